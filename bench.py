@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- rollouts/s of one full MPPI solve (sample + rollout + cost + beta/nabla + weighted
+update + shift) on synthetic point-mass data, BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4] [--chunks C]
+
+A "step" is one MPPI solve over one batch of rollouts.  Default workload = BASELINE configs[1]:
+point_mass2d, K = 1e4 rollouts, T = 200 steps, per GPU (weak scaling: with N GPUs the global
+batch is N*K, sharded by sample; the only exchange is one all-gather of T*A+2 floats per solve).
+Inputs are resident on the device before the timed region; the timed region is bracketed by a
+barrier + torch.cuda.synchronize() on both sides; value = N*K*steps / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the rollout kernel (dominant): algorithmic HBM bytes per launch / its mean
+                duration from HIP events recorded on the launch stream inside the timed region
+  cpu_baseline  the serial CPU oracle (oracle/mppi_oracle.c + its own rocRAND-host sampler)
+                timed on this host on a bounded sample of the same workload, 1 thread
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (A, K per GPU, T, description)
+    "c2": (2, 10_000, 200, "point_mass2d K=1e4 T=200 (BASELINE configs[1])"),
+    "c3": (3, 100_000, 200, "point_mass3d K=1e5 T=200 (BASELINE configs[2])"),
+    "c4": (3, 125_000, 200, "point_mass3d K=1e6/8 per GPU T=200 (BASELINE configs[3] shard)"),
+    "c1": (1, 100, 50, "point_mass1d K=100 T=50 (BASELINE configs[0] shape, on the GPU)"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def algorithmic_bytes_rollout(K, T, A):
+    """Bytes the rollout launch must move for K rollouts in this engine's dataflow:
+    one E store (4*T*A) + one cost store (4) per rollout.  SURVEY section 8(d)'s per-rollout
+    figure 2*4*T*A + 2R + 16 minus what the design removes: the E re-load (update fused into
+    the rollout), the RNG state (R = 0, counter-based Philox) and the three cost re-loads."""
+    return K * (4 * T * A + 4)
+
+
+def cpu_baseline(A, K, T, budget_s=12.0):
+    """Serial oracle, full solve incl. its own sampler, same K/T; returns rollouts/s."""
+    import numpy as np
+    import oracle_lib as ol
+    c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)
+    sig = [0.025] * A
+    U = c["U"].copy()
+    n = 0
+    t_tot = 0.0
+    while t_tot < budget_s and n < 200:
+        t0 = time.perf_counter()
+        E = ol.noise(0, n, 0, K, T, A, sig)
+        out = ol.solve(c["x0"], U, E, c["goal"], c["w"], c["dt"], f64_update=False)
+        t_tot += time.perf_counter() - t0
+        U = out["U"]
+        n += 1
+    assert np.isfinite(U).all()
+    return K * n / t_tot, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--strict", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import oracle_lib as ol
+    from mppi_gpu_amd import PointMassModel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    N = args.gpus
+    if world != N:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    A, K, T, desc = WORKLOADS[args.workload]
+    c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)      # x0 ~ 0.1 N(0,1), U0 = 0, yaml goal/w
+
+    if N == 1:
+        m = PointMassModel(K, T, float(c["dt"]), 2 * A, A)
+    else:
+        m = PointMassModel(K, T, float(c["dt"]), 2 * A, A, k_offset=rank * K)
+    m.set_tuning(chunks=args.chunks, strict=args.strict, max_blocks=args.max_blocks)
+    m.set_seed(0)
+    m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+    geo = m.geometry()
+
+    stream = torch.cuda.current_stream().cuda_stream if N > 1 else None
+    if N > 1:
+        L = m.partial_len()
+        partial = torch.zeros(L, device="cuda", dtype=torch.float32)
+        gathered = torch.zeros(N * L, device="cuda", dtype=torch.float32)
+
+        def step():
+            m.solve_local_async(partial.data_ptr(), stream)
+            dist.all_gather_into_tensor(gathered, partial)
+            m.solve_finish_async(gathered.data_ptr(), N, stream)
+    else:
+        def step():
+            m.solve_async()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_events:
+        m.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt_s = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = float(tt.item())
+    act = m.sync_act()
+    assert np.isfinite(act).all(), "non-finite action"
+
+    roof = None
+    if not args.no_events:
+        k_ms, k_n = m.kernel_ms(0)
+        c_ms, _ = m.kernel_ms(1)
+        ab = algorithmic_bytes_rollout(K, T, A)
+        ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_rollout_fused" if not geo["strict"] else "k_rollout_stream",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
+                "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
+
+    if rank == 0:
+        value = N * K * args.steps / dt_s
+        line = {
+            "metric": "rollouts/sec (K x T steps) per MPPI solve",
+            "value": value, "unit": "rollouts/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_s / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
+                       "global_rollouts": N * K, "sharding": f"samples x{N}",
+                       "geometry": geo, "rollout_steps_per_s": value * T},
+            "roofline": roof,
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            v, nsolves = cpu_baseline(A, K, T)
+            line["cpu_baseline"] = {
+                "value": v, "unit": "rollouts/s", "cores": 1, "kind": "port",
+                "sample": f"{nsolves} full serial solves of the same workload (K={K}, T={T}, A={A}), "
+                          "oracle/mppi_oracle.c + rocRAND-host Philox sampler, 1 thread"}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * mppi_gpu_amd.h -- C ABI of the MI355X MPPI rollout-and-update engine.
+ *
+ * This is the drop-in boundary for the hot path of NicolayP/mppi_gpu: one MPPI solve
+ * (PointMassModel::get_act, reference src/point_mass.cu:129-203) plus the data-in/data-out
+ * calls around it.  Every entry point below replaces one public member of the reference's
+ * `class PointMassModel` (reference include/point_mass.hpp:23-44); the C++ class of the same
+ * name shipped in include/point_mass.hpp is a thin veneer over these functions.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `float*` is a HOST pointer owned by the caller
+ *     unless its name starts with `d_` (device pointer, caller-owned, on the engine's GPU);
+ *   - layouts are the reference's: X[k][t][s] with T+1 rows per sample, E[k][t][a], U[t][a];
+ *     state = positions then velocities, S == 2*A, A in 1..4;
+ *   - return value: 0 on success, a negative MPPI_E* code otherwise; mppi_last_error() holds
+ *     the message.  (The reference prints "API error failed file:line" and exit(1)s,
+ *     include/mppi_utils.hpp:19-25; the C++ veneer keeps that behaviour, the C ABI leaves the
+ *     decision to the caller.)
+ *   - an engine is bound to one GPU and one host thread at a time, like the reference.
+ *   - there is NO CPU fallback: without a usable HIP device mppi_create fails with
+ *     MPPI_ENODEV.
+ */
+#ifndef MPPI_GPU_AMD_H_
+#define MPPI_GPU_AMD_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mppi_engine mppi_engine;
+
+enum {
+    MPPI_OK = 0,
+    MPPI_EINVAL = -1,   /* bad argument (dims, null pointer, unsupported A) */
+    MPPI_ENODEV = -2,   /* no usable HIP device / runtime failure at start-up */
+    MPPI_EHIP = -3,     /* a HIP runtime call failed; see mppi_last_error() */
+    MPPI_ESTATE = -4    /* call out of protocol (e.g. get_act before set_data) */
+};
+
+/* ---- reference surface ------------------------------------------------------------- */
+
+/* PointMassModel::PointMassModel(nb_sim, steps, dt, state_dim, act_dim, verbose)
+ * reference include/point_mass.hpp:25-30, src/point_mass.cu:19-106.  Uses the current HIP
+ * device.  lambda = 1, sigma = 0.025, inv_s = 1 as hard-coded in the reference
+ * (src/point_mass.cu:53-54, src/point_mass_gpu.cu:58-61,86). */
+int mppi_create(int nb_sim, int steps, float dt, int state_dim, int act_dim, int verbose,
+                mppi_engine** out);
+
+/* PointMassModel::~PointMassModel, src/point_mass.cu:108-127 */
+void mppi_destroy(mppi_engine* e);
+
+/* PointMassModel::memcpy_set_data(x, u, goal, w), src/point_mass.cu:205-228: uploads x0[S],
+ * U[T*A], goal[S], w[S] and (re)starts the noise stream (the reference re-runs curand_init
+ * there, :780). */
+int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* goal,
+                  const float* w);
+
+/* PointMassModel::set_x(x), src/point_mass.cu:482-486 */
+int mppi_set_x(mppi_engine* e, const float* x0);
+
+/* PointMassModel::get_x(x): declared at include/point_mass.hpp:34, never defined in the
+ * reference; defined here as the read-back of the current x0[S]. */
+int mppi_get_x(mppi_engine* e, float* x0);
+
+/* PointMassModel::get_act(next_act), src/point_mass.cu:129-203: one full solve
+ * (sample + rollout + cost, beta, nabla, weighted update), returns U[0,:] of the UPDATED
+ * sequence in next_act[A], then shifts U left by one step.  Blocking, like the reference. */
+int mppi_get_act(mppi_engine* e, float* next_act);
+
+/* PointMassModel::get_u(u), src/point_mass.cu:488-491: current U[T*A] */
+int mppi_get_u(mppi_engine* e, float* u);
+
+/* PointMassModel::memcpy_get_data(x_all, e), src/point_mass.cu:230-234:
+ * X[K*(T+1)*S] and E[K*T*A] of the LAST solve.  X is recomputed on demand from E (the timed
+ * path does not store X). */
+int mppi_get_data(mppi_engine* e, float* x_all, float* noise);
+
+/* PointMassModel::get_inf(x, u, e, cost, beta, nabla, weight), src/point_mass.cu:236-262.
+ * Any pointer may be NULL to skip that output. u is the current (updated, shifted) U. */
+int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* cost,
+                 float* beta, float* nabla, float* weight);
+
+/* ---- extensions (not in the reference) ---------------------------------------------- */
+
+/* lambda, per-axis noise sigma[A] and control-cost inv_s[A]; NULL keeps the current value.
+ * The reference parses these from YAML but never passes them on. */
+int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const float* inv_s);
+
+/* seed of the Philox stream (default 0); takes effect at the next mppi_set_data or call. */
+int mppi_set_seed(mppi_engine* e, unsigned long long seed);
+
+/* Injected-noise mode: the next solves use this E[K*T*A] instead of sampling (parity tests;
+ * the reference exposes E as an I/O buffer, src/point_mass.cu:232,251). NULL = sample again. */
+int mppi_set_noise(mppi_engine* e, const float* noise);
+
+/* Reproduce the reference's update_act sample-coverage defect for act_dim == 3
+ * (src/point_mass.cu:387,402,839-842). Default off = mathematically
+ * correct update. */
+int mppi_set_ref_compat(mppi_engine* e, int on);
+
+/* Kernel shape. chunks = lanes cooperating on one trajectory (power of two, 1..64; 0 = auto);
+ * strict != 0 selects the sequential, association-faithful rollout kernel (one lane per
+ * trajectory, cost bit-identical to the serial reference arithmetic), used as the parity
+ * anchor.  max_blocks caps the persistent grid (0 = auto). */
+int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
+
+/* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */
+
+/* Enqueue one full solve on `stream` (a hipStream_t, NULL = the engine's own stream) and
+ * return without waiting.  The action lands in a pinned host word readable after
+ * mppi_sync_act.  Solves on one engine are ordered on the stream. */
+int mppi_solve_async(mppi_engine* e, void* stream);
+
+/* Wait for everything enqueued by this engine and copy the last action into next_act[A]. */
+int mppi_sync_act(mppi_engine* e, float* next_act);
+
+/* Sharded solve (one engine per GPU, samples k_offset .. k_offset+nb_sim-1 of a global
+ * batch).  Step 1 enqueues sampling, rollout and the rank-local reduction and writes
+ * mppi_partial_len() floats [beta_g, S_g, N_g[T*A]] to the DEVICE buffer d_partial.
+ * The caller all-gathers the G partials (RCCL); step 2 combines them in rank order,
+ * updates and shifts U identically on every rank. */
+int mppi_create_shard(int nb_sim_local, long long k_offset, int steps, float dt, int state_dim,
+                      int act_dim, int verbose, mppi_engine** out);
+int mppi_partial_len(const mppi_engine* e);
+int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream);
+int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------- */
+
+/* When on, every solve records HIP events around its kernels on the launch stream. */
+int mppi_set_profiling(mppi_engine* e, int on);
+/* Average duration in ms of kernel `which` (0 = rollout, 1 = combine) over the solves since
+ * profiling was switched on; *n_out = number of launches averaged. Synchronises. */
+int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);
+/* Launch geometry actually in use: chunks, blocks per chunk (nq), grid, block, strict. */
+int mppi_get_geometry(mppi_engine* e, int out[5]);
+
+int mppi_device_count(void);
+const char* mppi_last_error(void);
+const char* mppi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_GPU_AMD_H_ */

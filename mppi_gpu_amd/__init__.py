@@ -1,0 +1,198 @@
+"""mppi_gpu_amd -- MI355X-native MPPI rollout-and-update engine (point-mass systems).
+
+Host-side mirror of the reference's controller interface for tests, the benchmark and Python
+callers.  `PointMassModel` has the public members of the reference's C++ class of the same
+name (reference include/point_mass.hpp:23-44) with numpy arrays in place of raw float
+pointers; every call goes straight through the C ABI (include/mppi_gpu_amd.h) into the HIP
+library.  Nothing here computes anything on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MppiError, check  # noqa: F401
+
+__all__ = ["PointMassModel", "MppiError", "device_count", "version"]
+
+
+def _fp(a):
+    return a.ctypes.data_as(_capi.c_float_p)
+
+
+def _f32(a, n, name):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"{name}: expected {n} floats, got {a.size}")
+    return a
+
+
+def device_count():
+    return _capi.load().mppi_device_count()
+
+
+def version():
+    return _capi.load().mppi_version().decode()
+
+
+class PointMassModel:
+    """reference `class PointMassModel` (include/point_mass.hpp:23-44).
+
+    PointMassModel(nb_sim, steps, dt, state_dim, act_dim, verbose=False)
+    k_offset != None creates a shard of a larger global batch (multi-GPU path).
+    """
+
+    def __init__(self, nb_sim, steps, dt, state_dim, act_dim, verbose=False, k_offset=None):
+        self._lib = _capi.load()
+        self._h = _capi.engine_p()
+        self.K, self.T, self.S, self.A = int(nb_sim), int(steps), int(state_dim), int(act_dim)
+        if k_offset is None:
+            rc = self._lib.mppi_create(self.K, self.T, float(dt), self.S, self.A, int(verbose),
+                                       C.byref(self._h))
+        else:
+            rc = self._lib.mppi_create_shard(self.K, int(k_offset), self.T, float(dt), self.S,
+                                             self.A, int(verbose), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.mppi_last_error().decode(errors="replace")
+            if self._h:
+                self._lib.mppi_destroy(self._h)
+                self._h = _capi.engine_p()
+            raise MppiError(rc, msg)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mppi_destroy(self._h)
+            self._h = _capi.engine_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- reference surface ------------------------------------------------------------------
+    def memcpy_set_data(self, x, u, goal, w):
+        """reference src/point_mass.cu:205-228"""
+        x = _f32(x, self.S, "x")
+        u = _f32(u, self.T * self.A, "u")
+        goal = _f32(goal, self.S, "goal")
+        w = _f32(w, self.S, "w")
+        check(self._lib.mppi_set_data(self._h, _fp(x), _fp(u), _fp(goal), _fp(w)))
+
+    def set_x(self, x):
+        """reference src/point_mass.cu:482-486"""
+        x = _f32(x, self.S, "x")
+        check(self._lib.mppi_set_x(self._h, _fp(x)))
+
+    def get_x(self):
+        """declared in reference include/point_mass.hpp:34 (never defined there)"""
+        x = np.empty(self.S, np.float32)
+        check(self._lib.mppi_get_x(self._h, _fp(x)))
+        return x
+
+    def get_act(self):
+        """One full MPPI solve; reference src/point_mass.cu:129-203. Returns next_act[A]."""
+        act = np.empty(self.A, np.float32)
+        check(self._lib.mppi_get_act(self._h, _fp(act)))
+        return act
+
+    def get_u(self):
+        """reference src/point_mass.cu:488-491"""
+        u = np.empty((self.T, self.A), np.float32)
+        check(self._lib.mppi_get_u(self._h, _fp(u)))
+        return u
+
+    def memcpy_get_data(self):
+        """reference src/point_mass.cu:230-234 -> (X[K][T+1][S], E[K][T][A])"""
+        X = np.empty((self.K, self.T + 1, self.S), np.float32)
+        E = np.empty((self.K, self.T, self.A), np.float32)
+        check(self._lib.mppi_get_data(self._h, _fp(X), _fp(E)))
+        return X, E
+
+    def get_inf(self, x=True, u=True, e=True, cost=True, beta=True, nabla=True, weight=True):
+        """reference src/point_mass.cu:236-262; returns a dict of the requested arrays."""
+        out = {}
+        null = C.cast(None, _capi.c_float_p)
+        X = np.empty((self.K, self.T + 1, self.S), np.float32) if x else None
+        U = np.empty((self.T, self.A), np.float32) if u else None
+        E = np.empty((self.K, self.T, self.A), np.float32) if e else None
+        cst = np.empty(self.K, np.float32) if cost else None
+        b = np.empty(1, np.float32) if beta else None
+        n = np.empty(1, np.float32) if nabla else None
+        wt = np.empty(self.K, np.float32) if weight else None
+        args = [(_fp(a) if a is not None else null) for a in (X, U, E, cst, b, n, wt)]
+        check(self._lib.mppi_get_inf(self._h, *args))
+        for name, a in (("x", X), ("u", U), ("e", E), ("cost", cst), ("weight", wt)):
+            if a is not None:
+                out[name] = a
+        if b is not None:
+            out["beta"] = float(b[0])
+        if n is not None:
+            out["nabla"] = float(n[0])
+        return out
+
+    # -- extensions -------------------------------------------------------------------------
+    def set_params(self, lam=1.0, sigma=None, inv_s=None):
+        null = C.cast(None, _capi.c_float_p)
+        s = _f32(sigma, self.A, "sigma") if sigma is not None else None
+        i = _f32(inv_s, self.A, "inv_s") if inv_s is not None else None
+        check(self._lib.mppi_set_params(self._h, float(lam), _fp(s) if s is not None else null,
+                                        _fp(i) if i is not None else null))
+
+    def set_seed(self, seed):
+        check(self._lib.mppi_set_seed(self._h, int(seed)))
+
+    def set_noise(self, E):
+        if E is None:
+            check(self._lib.mppi_set_noise(self._h, C.cast(None, _capi.c_float_p)))
+            return
+        E = _f32(E, self.K * self.T * self.A, "E")
+        check(self._lib.mppi_set_noise(self._h, _fp(E)))
+
+    def set_ref_compat(self, on):
+        check(self._lib.mppi_set_ref_compat(self._h, int(bool(on))))
+
+    def set_tuning(self, chunks=0, strict=False, max_blocks=0):
+        check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
+
+    def geometry(self):
+        g = (C.c_int * 5)()
+        check(self._lib.mppi_get_geometry(self._h, g))
+        return {"chunks": g[0], "nq": g[1], "grid": g[2], "block": g[3], "strict": bool(g[4])}
+
+    # -- asynchronous / sharded ---------------------------------------------------------------
+    def solve_async(self, stream=None):
+        check(self._lib.mppi_solve_async(self._h, C.c_void_p(stream or 0)))
+
+    def sync_act(self):
+        act = np.empty(self.A, np.float32)
+        check(self._lib.mppi_sync_act(self._h, _fp(act)))
+        return act
+
+    def partial_len(self):
+        return self._lib.mppi_partial_len(self._h)
+
+    def solve_local_async(self, d_partial_ptr, stream=None):
+        check(self._lib.mppi_solve_local_async(self._h, C.c_void_p(d_partial_ptr),
+                                               C.c_void_p(stream or 0)))
+
+    def solve_finish_async(self, d_gathered_ptr, n_parts, stream=None):
+        check(self._lib.mppi_solve_finish_async(self._h, C.c_void_p(d_gathered_ptr), int(n_parts),
+                                                C.c_void_p(stream or 0)))
+
+    # -- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on):
+        check(self._lib.mppi_set_profiling(self._h, int(bool(on))))
+
+    def kernel_ms(self, which):
+        avg = C.c_double()
+        n = C.c_int()
+        check(self._lib.mppi_kernel_ms(self._h, int(which), C.byref(avg), C.byref(n)))
+        return avg.value, n.value

@@ -1,0 +1,80 @@
+"""ctypes binding of the C ABI declared in include/mppi_gpu_amd.h.
+
+Loads mppi_gpu_amd/lib/libmppi_gpu_amd.so (built in-tree by `__graft_entry__.build()` or
+`make -C mppi_gpu_amd/csrc`).  There is no fallback of any kind: if the library is missing
+this module raises at import of the symbol table, and if no HIP device is usable
+`mppi_create` returns MPPI_ENODEV, which the wrappers turn into an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmppi_gpu_amd.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_double_p = C.POINTER(C.c_double)
+engine_p = C.c_void_p
+
+# name -> (restype, argtypes); one row per declaration in include/mppi_gpu_amd.h
+SIGNATURES = {
+    "mppi_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                              C.POINTER(engine_p)]),
+    "mppi_create_shard": (C.c_int, [C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(engine_p)]),
+    "mppi_destroy": (None, [engine_p]),
+    "mppi_set_data": (C.c_int, [engine_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "mppi_set_x": (C.c_int, [engine_p, c_float_p]),
+    "mppi_get_x": (C.c_int, [engine_p, c_float_p]),
+    "mppi_get_act": (C.c_int, [engine_p, c_float_p]),
+    "mppi_get_u": (C.c_int, [engine_p, c_float_p]),
+    "mppi_get_data": (C.c_int, [engine_p, c_float_p, c_float_p]),
+    "mppi_get_inf": (C.c_int, [engine_p] + [c_float_p] * 7),
+    "mppi_set_params": (C.c_int, [engine_p, C.c_float, c_float_p, c_float_p]),
+    "mppi_set_seed": (C.c_int, [engine_p, C.c_ulonglong]),
+    "mppi_set_noise": (C.c_int, [engine_p, c_float_p]),
+    "mppi_set_ref_compat": (C.c_int, [engine_p, C.c_int]),
+    "mppi_set_tuning": (C.c_int, [engine_p, C.c_int, C.c_int, C.c_int]),
+    "mppi_solve_async": (C.c_int, [engine_p, C.c_void_p]),
+    "mppi_sync_act": (C.c_int, [engine_p, c_float_p]),
+    "mppi_partial_len": (C.c_int, [engine_p]),
+    "mppi_solve_local_async": (C.c_int, [engine_p, C.c_void_p, C.c_void_p]),
+    "mppi_solve_finish_async": (C.c_int, [engine_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mppi_set_profiling": (C.c_int, [engine_p, C.c_int]),
+    "mppi_kernel_ms": (C.c_int, [engine_p, C.c_int, c_double_p, c_int_p]),
+    "mppi_get_geometry": (C.c_int, [engine_p, c_int_p]),
+    "mppi_device_count": (C.c_int, []),
+    "mppi_last_error": (C.c_char_p, []),
+    "mppi_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library with prototypes set; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C mppi_gpu_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MppiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mppi_gpu_amd error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise MppiError(rc, load().mppi_last_error().decode(errors="replace"))

@@ -1,0 +1,643 @@
+// engine.hip -- host side of the engine and its C ABI (include/mppi_gpu_amd.h).
+//
+// One Engine owns every device buffer of one MPPI controller, like the reference's
+// PointMassModel (include/point_mass.hpp:23-116) -- but as flat structure-of-arrays buffers:
+// no per-sample objects, no device heap, no host loop over the horizon, no synchronisation
+// between the stages of a solve (reference src/point_mass.cu:129-203 syncs 8 times and
+// launches >= 3*T kernels per solve).  A solve is two launches on one stream.
+#include "../../include/mppi_gpu_amd.h"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t err__ = (expr);                                                            \
+        if (err__ != hipSuccess)                                                              \
+            return fail(MPPI_EHIP, "HIP error %d (%s) at %s:%d: %s", (int)err__,              \
+                        hipGetErrorString(err__), __FILE__, __LINE__, #expr);                 \
+    } while (0)
+
+int next_pow2(int x)
+{
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+int ilog2(int x)
+{
+    int l = 0;
+    while ((1 << l) < x) ++l;
+    return l;
+}
+
+}  // namespace
+
+struct mppi_engine {
+    // problem
+    int K = 0, T = 0, S = 0, A = 0, TA = 0, SPB = 0, W = 0, NBT = 0;
+    long long k_offset = 0;
+    bool sharded = false;
+    float dt = 0.f, B0 = 0.f, lambda = 1.f;
+    float sigma[4] = {0.025f, 0.025f, 0.025f, 0.025f};
+    float inv_s[4] = {1.f, 1.f, 1.f, 1.f};
+    float goal[8] = {0}, w[8] = {0}, x0[8] = {0}, x0_last[8] = {0};
+    unsigned long long seed = 0;
+    unsigned long long solve_idx = 0;       // solves since set_data
+    bool data_set = false, have_solve = false;
+    bool ref_compat = false;
+    int verbose = 0;
+
+    // geometry
+    int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
+    bool geom_ok = false;
+    int C = 1, logC = 0, nq = 0, NQt = 0, n_tileblk = 0, grid = 0, strict = 0;
+    // geometry the stored noise / partials belong to
+    int last_C = 1, last_nq = 0;
+    unsigned long long last_idx = 0;
+
+    // device memory
+    mppi::DevState* d_state = nullptr;
+    float* d_U = nullptr;       // 2 x TA
+    float* d_Eint = nullptr;
+    size_t eint_floats = 0;
+    float* d_cost = nullptr;
+    float *d_pm = nullptr, *d_ps = nullptr, *d_pN = nullptr;
+    int part_cap = 0;
+    float* d_act = nullptr;
+    float* h_act = nullptr;     // pinned + mapped
+    float* h_act_dev = nullptr; // device alias of h_act
+    float* d_local_partial = nullptr;  // TA+2 (sharded path)
+    float* d_Einj = nullptr;    // injected noise, [K][T][A]
+    bool injected = false, inj_dirty = false;
+    float* d_scratch = nullptr; // export / trace / weights scratch
+    size_t scratch_floats = 0;
+
+    hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the most recent enqueue
+
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;     // 3 per solve: before rollout, after rollout, after combine
+    size_t ev_used = 0;
+};
+
+namespace {
+
+using mppi_engine_t = mppi_engine;
+
+int ensure_scratch(mppi_engine_t* e, size_t floats)
+{
+    if (e->scratch_floats >= floats) return MPPI_OK;
+    if (e->d_scratch) HIPCHK(hipFree(e->d_scratch));
+    e->d_scratch = nullptr;
+    e->scratch_floats = 0;
+    HIPCHK(hipMalloc(&e->d_scratch, floats * sizeof(float)));
+    e->scratch_floats = floats;
+    return MPPI_OK;
+}
+
+// Choose lanes-per-trajectory C, blocks-per-lane nq, the persistent grid; (re)allocate what
+// depends on them.
+int ensure_geometry(mppi_engine_t* e)
+{
+    if (e->geom_ok) return MPPI_OK;
+    const int NBT = e->NBT;
+    int C, nq, NQt = 0, strict = e->user_strict ? 1 : 0;
+    if (strict) {
+        C = 1;
+        nq = NBT;
+    } else {
+        const int nq_max = (e->A == 3) ? 25 : 20;
+        const int Cmin = next_pow2((NBT + nq_max - 1) / nq_max);
+        if (Cmin > 64)
+            return fail(MPPI_EINVAL, "horizon too long for the register-resident kernel: %d steps",
+                        e->T);
+        if (e->user_chunks > 0) {
+            C = e->user_chunks;
+            if (C < Cmin || C > 64 || (C & (C - 1)))
+                return fail(MPPI_EINVAL, "chunks must be a power of two in [%d, 64], got %d", Cmin,
+                            C);
+        } else {
+            // fill the chip: aim for >= 2048 wavefronts, keep >= 4 Philox blocks per lane
+            C = Cmin;
+            while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NBT + 2 * C - 1) / (2 * C) >= 4)
+                C <<= 1;
+        }
+        nq = (NBT + C - 1) / C;
+        NQt = mppi::rollout_pick_nq_template(e->A, nq);
+        if (!NQt) return fail(MPPI_EINVAL, "no kernel for %d blocks per lane", nq);
+    }
+    const long long lanes = (long long)e->K * C;
+    const long long ntb = (lanes + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
+    if (ntb > 0x7fffffffLL) return fail(MPPI_EINVAL, "too many samples");
+    int max_blocks = e->user_max_blocks > 0 ? e->user_max_blocks : 2048;
+    if (max_blocks > mppi::kMaxParts) max_blocks = mppi::kMaxParts;
+    const int grid = (int)(ntb < max_blocks ? ntb : max_blocks);
+
+    const size_t lds = mppi::rollout_lds_bytes(NBT, C * nq * e->W);
+    if (lds > 64 * 1024)
+        return fail(MPPI_EINVAL, "LDS need %zu B exceeds 64 KiB (T=%d A=%d C=%d)", lds, e->T, e->A,
+                    C);
+
+    const size_t need = (size_t)ntb * 4 * nq * 64 * e->W;
+    if (need > e->eint_floats) {
+        if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
+        e->d_Eint = nullptr;
+        e->eint_floats = 0;
+        HIPCHK(hipMalloc(&e->d_Eint, need * sizeof(float)));
+        e->eint_floats = need;
+    }
+    HIPCHK(hipMemsetAsync(e->d_Eint, 0, e->eint_floats * sizeof(float), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (grid > e->part_cap) {
+        if (e->d_pm) HIPCHK(hipFree(e->d_pm));
+        if (e->d_ps) HIPCHK(hipFree(e->d_ps));
+        if (e->d_pN) HIPCHK(hipFree(e->d_pN));
+        e->d_pm = e->d_ps = e->d_pN = nullptr;
+        HIPCHK(hipMalloc(&e->d_pm, (size_t)grid * sizeof(float)));
+        HIPCHK(hipMalloc(&e->d_ps, (size_t)grid * sizeof(float)));
+        HIPCHK(hipMalloc(&e->d_pN, (size_t)grid * e->TA * sizeof(float)));
+        e->part_cap = grid;
+    }
+    e->C = C;
+    e->logC = ilog2(C);
+    e->nq = nq;
+    e->NQt = NQt;
+    e->strict = strict;
+    e->n_tileblk = (int)ntb;
+    e->grid = grid;
+    e->geom_ok = true;
+    e->inj_dirty = e->injected;
+    return MPPI_OK;
+}
+
+long long ref_cover(const mppi_engine_t* e)
+{
+    if (!e->ref_compat || e->A != 3) return 0x7fffffffffffffffLL;
+    long long cov = 512LL * (e->K / 768 + 1);   // reference src/point_mass.cu:387,402,839-842
+    return cov < e->K ? cov : e->K;
+}
+
+void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
+{
+    a.dev = e->d_state;
+    a.U = e->d_U;
+    a.Eint = e->d_Eint;
+    a.cost = e->d_cost;
+    a.part_m = e->d_pm;
+    a.part_s = e->d_ps;
+    a.part_N = e->d_pN;
+    a.k_offset = e->k_offset;
+    a.k_cover = ref_cover(e);
+    a.seed = e->seed;
+    a.solve_idx = e->solve_idx;
+    a.K = e->K;
+    a.T = e->T;
+    a.TA = e->TA;
+    a.NBT = e->NBT;
+    a.C = e->C;
+    a.logC = e->logC;
+    a.nq = e->nq;
+    a.n_tileblk = e->n_tileblk;
+    a.dt = e->dt;
+    a.B0 = e->B0;
+    a.lambda = e->lambda;
+    a.inv_lambda = 1 / e->lambda;
+    for (int i = 0; i < 8; ++i) { a.goal[i] = e->goal[i]; a.w[i] = e->w[i]; }
+    for (int i = 0; i < 4; ++i) { a.sigma[i] = e->sigma[i]; a.inv_s[i] = e->inv_s[i]; }
+}
+
+int prof_event(mppi_engine_t* e, hipStream_t st)
+{
+    if (!e->prof) return MPPI_OK;
+    if (e->ev_used == e->ev.size()) {
+        if (e->ev.size() >= 3 * 8192) return MPPI_OK;   // stop recording, keep running
+        hipEvent_t ne;
+        HIPCHK(hipEventCreate(&ne));
+        e->ev.push_back(ne);
+    }
+    HIPCHK(hipEventRecord(e->ev[e->ev_used++], st));
+    return MPPI_OK;
+}
+
+// sampling / rollout / per-block reduction
+int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
+{
+    if (!e->data_set) return fail(MPPI_ESTATE, "solve before mppi_set_data");
+    e->last_stream = st;
+    int rc = ensure_geometry(e);
+    if (rc) return rc;
+    if (e->injected && e->inj_dirty) {
+        HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, e->C, e->nq, st));
+        e->inj_dirty = false;
+    }
+    mppi::RolloutArgs ra;
+    fill_rollout_args(e, ra);
+    if ((rc = prof_event(e, st))) return rc;
+    if (e->strict)
+        HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st));
+    else
+        HIPCHK(mppi::launch_rollout_fused(e->A, e->NQt, !e->injected, e->grid, ra, st));
+    if ((rc = prof_event(e, st))) return rc;
+    e->last_C = e->C;
+    e->last_nq = e->nq;
+    e->last_idx = e->solve_idx;
+    memcpy(e->x0_last, e->x0, sizeof e->x0);
+    return MPPI_OK;
+}
+
+int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const float* s,
+                    const float* N, long long ms, long long ss, long long Ns, int n_parts,
+                    bool final_mode, float* partial_out)
+{
+    if (n_parts < 1 || n_parts > mppi::kMaxParts)
+        return fail(MPPI_EINVAL, "n_parts %d out of range", n_parts);
+    mppi::CombineArgs ca;
+    ca.dev = e->d_state;
+    ca.m = m; ca.s = s; ca.N = N;
+    ca.m_stride = ms; ca.s_stride = ss; ca.N_stride = Ns;
+    ca.n_parts = n_parts;
+    ca.TA = e->TA;
+    ca.A = e->A;
+    ca.inv_lambda = 1 / e->lambda;
+    ca.U = e->d_U;
+    ca.act_dev = e->d_act;
+    ca.act_host = e->h_act_dev;
+    ca.partial_out = partial_out;
+    ca.solve_idx = e->solve_idx;
+    ca.final_mode = final_mode ? 1 : 0;
+    HIPCHK(mppi::launch_combine(ca, st));
+    return MPPI_OK;
+}
+
+int create_common(int K, long long k_offset, bool sharded, int T, float dt, int S, int A,
+                  int verbose, mppi_engine** out)
+{
+    if (!out) return fail(MPPI_EINVAL, "out is null");
+    *out = nullptr;
+    if (K < 1 || T < 1) return fail(MPPI_EINVAL, "nb_sim and steps must be >= 1");
+    if (A < 1 || A > 4) return fail(MPPI_EINVAL, "act_dim %d unsupported (1..4)", A);
+    if (S != 2 * A) return fail(MPPI_EINVAL, "state_dim must be 2*act_dim (got %d, %d)", S, A);
+    if (!(dt > 0.f)) return fail(MPPI_EINVAL, "dt must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(MPPI_ENODEV, "no HIP device: the engine has no CPU fallback");
+
+    mppi_engine* e = new mppi_engine();
+    e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
+    e->SPB = 4 / A; e->W = e->SPB * A;
+    e->NBT = (T + e->SPB - 1) / e->SPB;
+    e->k_offset = k_offset;
+    e->sharded = sharded;
+    e->dt = dt;
+    {
+        const float dd = dt * dt;                 // reference src/point_mass.cu:46
+        e->B0 = (float)((double)dd / 2.0);
+    }
+    e->verbose = verbose;
+    *out = e;   // so that a failing HIPCHK below still lets the caller destroy it
+
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&e->d_state, sizeof(mppi::DevState)));
+    HIPCHK(hipMemset(e->d_state, 0, sizeof(mppi::DevState)));
+    HIPCHK(hipMalloc(&e->d_U, 2 * (size_t)e->TA * sizeof(float)));
+    HIPCHK(hipMemset(e->d_U, 0, 2 * (size_t)e->TA * sizeof(float)));
+    HIPCHK(hipMalloc(&e->d_cost, (size_t)K * sizeof(float)));
+    HIPCHK(hipMalloc(&e->d_act, 4 * sizeof(float)));
+    HIPCHK(hipMalloc(&e->d_local_partial, (size_t)(e->TA + 2) * sizeof(float)));
+    HIPCHK(hipHostMalloc(&e->h_act, 4 * sizeof(float), hipHostMallocMapped));
+    memset(e->h_act, 0, 4 * sizeof(float));
+    HIPCHK(hipHostGetDevicePointer((void**)&e->h_act_dev, e->h_act, 0));
+    if (verbose)
+        printf("mppi_gpu_amd: K=%d T=%d S=%d A=%d dt=%g (offset %lld)\n", K, T, S, A, dt,
+               k_offset);
+    return MPPI_OK;
+}
+
+int sync_all(mppi_engine_t* e)
+{
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MPPI_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int mppi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mppi_last_error(void) { return g_last_error.c_str(); }
+const char* mppi_version(void) { return "mppi_gpu_amd 0.1 (gfx950)"; }
+
+int mppi_create(int nb_sim, int steps, float dt, int state_dim, int act_dim, int verbose,
+                mppi_engine** out)
+{
+    return create_common(nb_sim, 0, false, steps, dt, state_dim, act_dim, verbose, out);
+}
+
+int mppi_create_shard(int nb_sim_local, long long k_offset, int steps, float dt, int state_dim,
+                      int act_dim, int verbose, mppi_engine** out)
+{
+    if (k_offset < 0) return fail(MPPI_EINVAL, "k_offset < 0");
+    return create_common(nb_sim_local, k_offset, true, steps, dt, state_dim, act_dim, verbose, out);
+}
+
+void mppi_destroy(mppi_engine* e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    (void)hipFree(e->d_state);
+    (void)hipFree(e->d_U);
+    (void)hipFree(e->d_Eint);
+    (void)hipFree(e->d_cost);
+    (void)hipFree(e->d_pm);
+    (void)hipFree(e->d_ps);
+    (void)hipFree(e->d_pN);
+    (void)hipFree(e->d_act);
+    (void)hipFree(e->d_local_partial);
+    (void)hipFree(e->d_Einj);
+    (void)hipFree(e->d_scratch);
+    if (e->h_act) (void)hipHostFree(e->h_act);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* goal,
+                  const float* w)
+{
+    if (!e || !x0 || !u || !goal || !w) return fail(MPPI_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
+    e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
+    e->have_solve = false;
+    HIPCHK(hipMemcpy(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_U, u, (size_t)e->TA * sizeof(float), hipMemcpyHostToDevice));
+    e->data_set = true;
+    return MPPI_OK;
+}
+
+int mppi_set_x(mppi_engine* e, const float* x0)
+{
+    if (!e || !x0) return fail(MPPI_EINVAL, "null argument");
+    for (int i = 0; i < e->S; ++i) e->x0[i] = x0[i];
+    // ordered behind the solves already enqueued on the engine's stream
+    HIPCHK(hipMemcpyAsync(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MPPI_OK;
+}
+
+int mppi_get_x(mppi_engine* e, float* x0)
+{
+    if (!e || !x0) return fail(MPPI_EINVAL, "null argument");
+    float tmp[8];
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(tmp, e->d_state->x0, sizeof tmp, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->S; ++i) x0[i] = tmp[i];
+    return MPPI_OK;
+}
+
+int mppi_solve_async(mppi_engine* e, void* stream)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    int rc = enqueue_rollout(e, st);
+    if (rc) return rc;
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, true, nullptr);
+    if (rc) return rc;
+    if ((rc = prof_event(e, st))) return rc;
+    e->solve_idx += 1;
+    e->have_solve = true;
+    return MPPI_OK;
+}
+
+int mppi_sync_act(mppi_engine* e, float* next_act)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (e->last_stream && e->last_stream != e->stream)
+        HIPCHK(hipStreamSynchronize(e->last_stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (next_act)
+        for (int i = 0; i < e->A; ++i) next_act[i] = e->h_act[i];
+    return MPPI_OK;
+}
+
+int mppi_get_act(mppi_engine* e, float* next_act)
+{
+    if (!e || !next_act) return fail(MPPI_EINVAL, "null argument");
+    int rc = mppi_solve_async(e, nullptr);
+    if (rc) return rc;
+    return mppi_sync_act(e, next_act);
+}
+
+int mppi_get_u(mppi_engine* e, float* u)
+{
+    if (!e || !u) return fail(MPPI_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(u, e->d_U + (e->solve_idx & 1ull) * e->TA, (size_t)e->TA * sizeof(float),
+                     hipMemcpyDeviceToHost));
+    return MPPI_OK;
+}
+
+int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* cost, float* beta,
+                 float* nabla, float* weight)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if ((x_all || noise || cost || beta || nabla || weight) && !e->have_solve)
+        return fail(MPPI_ESTATE, "no solve has run since mppi_set_data");
+    int rc;
+    if (u && (rc = mppi_get_u(e, u))) return rc;
+    if (cost)
+        HIPCHK(hipMemcpy(cost, e->d_cost, (size_t)e->K * sizeof(float), hipMemcpyDeviceToHost));
+    if (beta || nabla) {
+        mppi::DevState hs;
+        HIPCHK(hipMemcpy(&hs, e->d_state, sizeof hs, hipMemcpyDeviceToHost));
+        if (beta) *beta = hs.beta;
+        if (nabla) *nabla = hs.nabla;
+    }
+    if (weight) {
+        if ((rc = ensure_scratch(e, (size_t)e->K))) return rc;
+        HIPCHK(mppi::launch_weights(e->d_cost, e->d_state, e->lambda, e->d_scratch, e->K,
+                                    e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(weight, e->d_scratch, (size_t)e->K * sizeof(float),
+                         hipMemcpyDeviceToHost));
+    }
+    if (noise) {
+        const size_t n = (size_t)e->K * e->T * e->A;
+        if ((rc = ensure_scratch(e, n))) return rc;
+        HIPCHK(mppi::launch_export_noise(e->A, e->d_Eint, e->d_scratch, e->K, e->T, e->last_C,
+                                         e->last_nq, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(noise, e->d_scratch, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (x_all) {
+        const size_t n = (size_t)e->K * (e->T + 1) * e->S;
+        // controls and x0 the last rollout used: U buffer of parity last_idx, x0_last
+        if ((rc = ensure_scratch(e, n + 8))) return rc;
+        float* d_x0 = e->d_scratch + n;
+        HIPCHK(hipMemcpy(d_x0, e->x0_last, 8 * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(mppi::launch_trace_states(e->A, e->d_Eint, e->d_U + (e->last_idx & 1ull) * e->TA,
+                                         d_x0, e->d_scratch, e->K, e->T, e->last_C, e->last_nq,
+                                         e->dt, e->B0, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(x_all, e->d_scratch, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return MPPI_OK;
+}
+
+int mppi_get_data(mppi_engine* e, float* x_all, float* noise)
+{
+    return mppi_get_inf(e, x_all, nullptr, noise, nullptr, nullptr, nullptr, nullptr);
+}
+
+int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const float* inv_s)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (!(lambda > 0.f)) return fail(MPPI_EINVAL, "lambda must be positive");
+    e->lambda = lambda;
+    if (sigma) for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
+    if (inv_s) for (int i = 0; i < e->A; ++i) e->inv_s[i] = inv_s[i];
+    return MPPI_OK;
+}
+
+int mppi_set_seed(mppi_engine* e, unsigned long long seed)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    e->seed = seed;
+    return MPPI_OK;
+}
+
+int mppi_set_noise(mppi_engine* e, const float* noise)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!noise) {
+        e->injected = false;
+        return MPPI_OK;
+    }
+    const size_t n = (size_t)e->K * e->T * e->A;
+    if (!e->d_Einj) HIPCHK(hipMalloc(&e->d_Einj, n * sizeof(float)));
+    HIPCHK(hipMemcpy(e->d_Einj, noise, n * sizeof(float), hipMemcpyHostToDevice));
+    e->injected = true;
+    e->inj_dirty = true;
+    return MPPI_OK;
+}
+
+int mppi_set_ref_compat(mppi_engine* e, int on)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (on && e->A == 1)
+        return fail(MPPI_EINVAL, "ref_compat for act_dim 1 is not implemented");
+    if (on && e->sharded) return fail(MPPI_EINVAL, "ref_compat is single-GPU only");
+    e->ref_compat = on != 0;
+    return MPPI_OK;
+}
+
+int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (chunks < 0 || max_blocks < 0) return fail(MPPI_EINVAL, "negative tuning value");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->user_chunks = chunks;
+    e->user_strict = strict;
+    e->user_max_blocks = max_blocks;
+    e->geom_ok = false;
+    int rc = ensure_geometry(e);
+    if (rc) e->geom_ok = false;
+    return rc;
+}
+
+int mppi_partial_len(const mppi_engine* e) { return e ? e->TA + 2 : 0; }
+
+int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
+{
+    if (!e || !d_partial) return fail(MPPI_EINVAL, "null argument");
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    int rc = enqueue_rollout(e, st);
+    if (rc) return rc;
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, false, d_partial);
+    if (rc) return rc;
+    return prof_event(e, st);
+}
+
+int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream)
+{
+    if (!e || !d_gathered) return fail(MPPI_EINVAL, "null argument");
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const long long stride = e->TA + 2;
+    int rc = enqueue_combine(e, st, d_gathered, d_gathered + 1, d_gathered + 2, stride, stride,
+                             stride, n_parts, true, nullptr);
+    if (rc) return rc;
+    e->solve_idx += 1;
+    e->have_solve = true;
+    return MPPI_OK;
+}
+
+int mppi_set_profiling(mppi_engine* e, int on)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->prof = on != 0;
+    e->ev_used = 0;
+    return MPPI_OK;
+}
+
+int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out)
+{
+    if (!e || !avg_ms || !n_out) return fail(MPPI_EINVAL, "null argument");
+    if (which < 0 || which > 1) return fail(MPPI_EINVAL, "which must be 0 or 1");
+    HIPCHK(hipDeviceSynchronize());
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 3 <= e->ev_used; i += 3) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[i + which], e->ev[i + which + 1]));
+        tot += ms;
+        ++n;
+    }
+    *avg_ms = n ? tot / n : 0.0;
+    *n_out = n;
+    return MPPI_OK;
+}
+
+int mppi_get_geometry(mppi_engine* e, int out[5])
+{
+    if (!e || !out) return fail(MPPI_EINVAL, "null argument");
+    int rc = ensure_geometry(e);
+    if (rc) return rc;
+    out[0] = e->C; out[1] = e->nq; out[2] = e->grid; out[3] = mppi::kRolloutThreads;
+    out[4] = e->strict;
+    return MPPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// kernels.hpp -- host-visible launch interface of the gfx950 kernels (kernels.hip).
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   DevState      : x0[8] (set_x writes it with one small H2D copy) and the observables
+//                   beta / nabla of the last solve.
+//   U             : 2 x [T*A] floats, double-buffered by solve_idx parity (in = idx&1).
+//   Eint          : noise in TILE layout: float[tiles][nq][64][W]; a tile is one wavefront's
+//                   64 lanes = 64/C trajectories x C time-chunks, lane = (k%(64/C))*C + c;
+//                   W = 4 (A=1,2,4) or 3 (A=3) floats = the normals of one Philox block.
+//                   Every store and load of it is a full-wave contiguous 1 KiB / 768 B access.
+//   cost          : [K] floats.
+//   part_m/part_s : [grid] per-block running min and exp-sum (relative to that min).
+//   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mppi {
+
+struct DevState {
+    float x0[8];
+    float beta;    // observables of the last finished solve
+    float nabla;
+};
+
+// Everything a rollout launch needs; passed by value (fits the kernarg segment).
+struct RolloutArgs {
+    const DevState* dev;
+    const float* U;        // base of the 2 x TA double buffer
+    float* Eint;           // tile-layout noise (written when sampling, read when injected)
+    float* cost;           // [K]
+    float* part_m;         // [grid]
+    float* part_s;         // [grid]
+    float* part_N;         // [grid][TA]
+    long long k_offset;    // global index of local sample 0 (Philox subsequence base)
+    long long k_cover;     // samples with GLOBAL index >= k_cover get zero update weight
+    unsigned long long seed;
+    unsigned long long solve_idx;   // solves since set_data: Philox offset, U buffer parity
+    int K;                 // local samples
+    int T;
+    int TA;                // T*A
+    int NBT;               // Philox blocks per sample per solve = ceil(T/spb)
+    int C;                 // lanes per trajectory (power of two)
+    int logC;
+    int nq;                // Philox blocks per lane (chunk length in blocks)
+    int n_tileblk;         // number of 256-lane tile groups = ceil(K*C/256)
+    float dt;
+    float B0;              // (float)(dt*dt/2.0)
+    float lambda;
+    float inv_lambda;      // 1/lambda (float)
+    float goal[8];
+    float w[8];
+    float sigma[4];
+    float inv_s[4];
+};
+
+struct CombineArgs {
+    DevState* dev;
+    const float* m;        // [n_parts] (stride m_stride floats)
+    const float* s;
+    const float* N;        // row p at N + p*N_stride, TA floats
+    long long m_stride, s_stride, N_stride;
+    int n_parts;
+    int TA;
+    int A;
+    float inv_lambda;
+    // final mode: update + shift U, publish action, bump solve_idx
+    float* U;              // base of the 2 x TA double buffer
+    float* act_dev;        // [4] device copy of the action
+    float* act_host;       // pinned, host-mapped; may be null
+    // partial mode: out[0]=beta_g, out[1]=S_g, out[2..2+TA)=N_g
+    float* partial_out;
+    unsigned long long solve_idx;
+    int final_mode;
+};
+
+constexpr int kRolloutThreads = 256;
+constexpr int kCombineThreads = 1024;
+constexpr int kCombineCols = 64;
+constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
+
+// Supported register-resident chunk lengths (template NQ); pick the smallest >= nq.
+int rollout_pick_nq_template(int A, int nq);     // returns 0 if nq is too large
+size_t rollout_lds_bytes(int NBT, int TAp);
+
+hipError_t launch_rollout_fused(int A, int NQt, bool sample, int grid, const RolloutArgs& a,
+                                hipStream_t st);
+hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
+                                 hipStream_t st);
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+
+// debug / data-movement kernels (off the timed path)
+hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T, int C,
+                               int nq, hipStream_t st);
+hipError_t launch_import_noise(int A, const float* E_ktA, float* Eint, int K, int T, int C,
+                               int nq, hipStream_t st);
+hipError_t launch_trace_states(int A, const float* Eint, const float* U_rollout, const float* x0,
+                               float* X, int K, int T, int C, int nq, float dt, float B0,
+                               hipStream_t st);
+hipError_t launch_weights(const float* cost, const DevState* dev, float lambda, float* wts,
+                          int K, hipStream_t st);
+
+}  // namespace mppi

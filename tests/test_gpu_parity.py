@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Floating point, so tolerances are stated here:
+
+  strict kernel  (one lane per trajectory, sequential)   cost: BIT-EXACT, beta: exact
+  fused kernel   (C lanes per trajectory, scan + tree)   cost: rtol 2e-6
+  both                                                   nabla: rtol 2e-6 (strict) / 1e-4 (fused)
+                                                         weights: rtol 2e-5 (strict) / 1e-3 (fused)
+                                                         U, action: max-norm rel 1e-5
+  (w_k = exp(-(c_k-beta)/lambda)/nabla, so an absolute cost difference d moves a weight by the
+  RELATIVE amount d/lambda: with costs of a few hundred, the fused kernel's ~1 ulp(cost)
+  re-association differences show up as ~1e-4 relative in single weights; they average out
+  in the controls, which is the quantity the 1e-5 bar is stated on.)
+                                                         (north_star: "controls ... to 1e-5 rel")
+The U criterion is |U_gpu - U_oracle|_inf <= 1e-5 * max(|U_oracle|_inf, sigma): element-wise
+relative error is meaningless where a control crosses zero.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SIGMA = 0.025
+
+
+def _model(gpu, A, K, T, case, chunks=0, strict=False, max_blocks=0):
+    from mppi_gpu_amd import PointMassModel
+    m = PointMassModel(K, T, float(case["dt"]), 2 * A, A)
+    m.set_tuning(chunks=chunks, strict=strict, max_blocks=max_blocks)
+    m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
+    return m
+
+
+def _check_solve(got_act, inf, ref, cost_exact, tag=""):
+    if cost_exact:
+        assert np.array_equal(inf["cost"], ref["cost"]), f"{tag}: cost not bit-exact"
+        assert np.float32(inf["beta"]) == ref["beta"], tag
+    else:
+        np.testing.assert_allclose(inf["cost"], ref["cost"], rtol=2e-6, atol=0, err_msg=tag)
+        np.testing.assert_allclose(inf["beta"], ref["beta"], rtol=2e-6, err_msg=tag)
+    np.testing.assert_allclose(inf["nabla"], ref["nabla"], rtol=2e-6 if cost_exact else 1e-4,
+                               err_msg=tag)
+    np.testing.assert_allclose(inf["weight"], ref["weights"], rtol=2e-5 if cost_exact else 1e-3,
+                               atol=1e-12, err_msg=tag)
+    scale = max(float(np.abs(ref["U"]).max()), SIGMA)
+    err = float(np.abs(inf["u"] - ref["U"]).max())
+    assert err <= 1e-5 * scale, f"{tag}: U max err {err:.3e} vs scale {scale:.3e}"
+    err_a = float(np.abs(got_act - ref["next_act"]).max())
+    assert err_a <= 1e-5 * scale, f"{tag}: action err {err_a:.3e}"
+
+
+CASES = [
+    # A, K, T
+    (1, 100, 50),      # BASELINE config 1 shape
+    (2, 3, 12),        # mppi-config-test.yaml shape
+    (2, 257, 50),
+    (2, 1000, 200),    # config 2 horizon
+    (3, 300, 51),
+    (3, 1024, 200),    # config 3 horizon
+    (4, 130, 37),
+    (1, 513, 203),     # ragged horizon for 4 steps per Philox block
+    (2, 64, 1),        # single step
+]
+
+
+@pytest.mark.parametrize("A,K,T", CASES)
+def test_strict_kernel_cost_bit_exact_and_update(gpu, A, K, T):
+    c = ol.make_case(A, K, T, seed=100 + A * 7 + T)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    with _model(gpu, A, K, T, c, strict=True) as m:
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf()
+        assert m.geometry()["strict"]
+    assert np.array_equal(inf["e"], c["E"]), "injected noise must round-trip through the tile layout"
+    _check_solve(act, inf, ref, cost_exact=True, tag=f"strict A{A} K{K} T{T}")
+
+
+@pytest.mark.parametrize("A,K,T", CASES)
+@pytest.mark.parametrize("chunks", [0, 1, 2, 8, 64])
+def test_fused_kernel_matches_oracle(gpu, A, K, T, chunks):
+    from mppi_gpu_amd import MppiError
+    c = ol.make_case(A, K, T, seed=200 + A * 7 + T)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    try:
+        m = _model(gpu, A, K, T, c, chunks=chunks)
+    except MppiError as ex:       # chunks below the register-resident minimum for this horizon
+        assert "chunks must be" in str(ex)
+        pytest.skip(str(ex))
+    with m:
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf()
+        geo = m.geometry()
+    assert not geo["strict"]
+    assert np.array_equal(inf["e"], c["E"])
+    _check_solve(act, inf, ref, cost_exact=False, tag=f"fused A{A} K{K} T{T} {geo}")
+
+
+def test_states_trace_matches_oracle(gpu):
+    A, K, T = 3, 200, 50
+    c = ol.make_case(A, K, T, seed=5)
+    cost, X = ol.rollout(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], want_X=True)
+    with _model(gpu, A, K, T, c, chunks=4) as m:
+        m.set_noise(c["E"])
+        m.get_act()
+        Xg, Eg = m.memcpy_get_data()
+    assert np.array_equal(Eg, c["E"])
+    assert np.array_equal(Xg, X), "state trace is sequential: bit-exact with the oracle"
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("solve_")))
+def test_committed_golden_fixtures(gpu, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    A, K, T = int(g["A"]), int(g["K"]), int(g["T"])
+    case = dict(x0=g["x0"], U=g["U"], goal=g["goal"], w=g["w"], dt=g["dt"])
+    ref = dict(cost=g["cost"], beta=np.float32(g["beta"]), nabla=np.float32(g["nabla"]),
+               weights=g["weights"], U=g["U_next"], next_act=g["next_act"])
+    for strict in (True, False):
+        with _model(gpu, A, K, T, case, strict=strict) as m:
+            m.set_noise(g["E"])
+            act = m.get_act()
+            inf = m.get_inf()
+        _check_solve(act, inf, ref, cost_exact=strict, tag=f"{name} strict={strict}")
+
+
+def test_sampled_noise_matches_rocrand_host_stream(gpu):
+    """Sampling mode: the device noise equals the stream stated over rocRAND's public host API
+    (same Philox words; Box-Muller differs only by GPU-vs-libm transcendental accuracy),
+    independent of the kernel geometry, and advances from solve to solve."""
+    A, K, T = 3, 500, 200
+    c = ol.make_case(A, K, T, seed=9)
+    sig = np.array([0.025, 0.05, 0.0125], np.float32)
+    Es = {}
+    for chunks, strict in ((0, False), (8, False), (32, False), (0, True)):
+        with _model(gpu, A, K, T, c, chunks=chunks, strict=strict) as m:
+            m.set_params(1.0, sigma=sig)
+            m.set_seed(1234)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.get_act()
+            e0 = m.get_inf(x=False, u=False, cost=False, beta=False, nabla=False, weight=False)["e"]
+            m.get_act()
+            e1 = m.get_inf(x=False, u=False, cost=False, beta=False, nabla=False, weight=False)["e"]
+        Es[(chunks, strict)] = (e0, e1)
+    base0, base1 = Es[(0, False)]
+    for key, (e0, e1) in Es.items():
+        assert np.array_equal(e0, base0) and np.array_equal(e1, base1), f"noise depends on geometry {key}"
+    h0 = ol.noise(1234, 0, 0, K, T, A, sig)
+    h1 = ol.noise(1234, 1, 0, K, T, A, sig)
+    # |z| <= 6.7; fast device sin/cos are accurate to ~1e-6 absolute on the unit circle
+    np.testing.assert_allclose(base0, h0, rtol=0, atol=float(sig.max()) * 2e-5)
+    np.testing.assert_allclose(base1, h1, rtol=0, atol=float(sig.max()) * 2e-5)
+    assert not np.array_equal(base0, base1)
+    z = base0 / sig
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+
+
+def test_closed_loop_sequence_matches_oracle_chain(gpu):
+    """Five consecutive solves in sampling mode with set_x in between: every solve is re-run
+    by the oracle on the noise the device drew (read back with get_inf)."""
+    A, K, T = 2, 2000, 50
+    c = ol.make_case(A, K, T, seed=21, u_scale=0.0)
+    x = c["x0"].copy()
+    U = c["U"].copy()
+    with _model(gpu, A, K, T, c) as m:
+        for it in range(5):
+            assert np.array_equal(m.get_u(), U) or it > 0
+            U_before = m.get_u()
+            act = m.get_act()
+            inf = m.get_inf(x=False)
+            ref = ol.solve(x, U_before, inf["e"], c["goal"], c["w"], c["dt"])
+            _check_solve(act, inf, ref, cost_exact=False, tag=f"step {it}")
+            # a stand-in plant: apply the action with the model itself
+            xn = x.copy()
+            xn[:A] = x[:A] + c["dt"] * x[A:] + np.float32(0.005) * act
+            xn[A:] = x[A:] + c["dt"] * act
+            x = xn.astype(np.float32)
+            m.set_x(x)
+            assert np.array_equal(m.get_x(), x)
+
+
+def test_persistent_grid_and_rescale_path(gpu):
+    """max_blocks << tiles forces every block through several tile groups, i.e. through the
+    running-minimum rescale branch; costs are spread so that block minima differ a lot."""
+    A, K, T = 2, 20000, 50
+    c = ol.make_case(A, K, T, seed=33, u_scale=0.3)
+    # make sample costs vary strongly: scale the noise of later samples up
+    ramp = np.linspace(1.0, 12.0, K, dtype=np.float32)[::-1].copy()
+    c["E"] = (c["E"] * ramp[:, None, None]).astype(np.float32)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    assert ref["cost"].max() - ref["cost"].min() > 30
+    for max_blocks in (1, 3, 64):
+        with _model(gpu, A, K, T, c, chunks=4, max_blocks=max_blocks) as m:
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf(x=False, e=False)
+            assert m.geometry()["grid"] == max_blocks
+        _check_solve(act, inf, ref, cost_exact=False, tag=f"max_blocks={max_blocks}")
+
+
+def test_extreme_cost_spread_underflow(gpu):
+    """exp underflow: one sample far better than all others -> weights ~ one-hot, no NaN."""
+    A, K, T = 2, 512, 20
+    c = ol.make_case(A, K, T, seed=44)
+    c["E"] = (c["E"] * 40).astype(np.float32)
+    c["E"][7] = 0
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    with _model(gpu, A, K, T, c) as m:
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf(x=False, e=False)
+    assert np.isfinite(inf["u"]).all()
+    _check_solve(act, inf, ref, cost_exact=False, tag="underflow")
+
+
+def test_all_equal_costs_degenerate(gpu):
+    """sigma = 0: all costs equal, weights uniform, dU = 0 -> U is shifted exactly."""
+    A, K, T = 3, 777, 30
+    c = ol.make_case(A, K, T, seed=55)
+    with _model(gpu, A, K, T, c) as m:
+        m.set_params(1.0, sigma=[0, 0, 0])
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        act = m.get_act()
+        inf = m.get_inf(x=False)
+    assert np.all(inf["e"] == 0)
+    assert np.all(inf["cost"] == inf["cost"][0])
+    np.testing.assert_allclose(inf["weight"], 1.0 / K, rtol=1e-6)
+    assert np.array_equal(act, c["U"][0])
+    assert np.array_equal(inf["u"][:-1], c["U"][1:]) and np.array_equal(inf["u"][-1], c["U"][-1])
+
+
+def test_params_lambda_inv_s(gpu):
+    A, K, T = 2, 400, 25
+    c = ol.make_case(A, K, T, seed=66)
+    lam, inv_s = 1.5, np.array([2.0, 0.5], np.float32)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=lam, inv_s=inv_s)
+    for strict in (True, False):
+        with _model(gpu, A, K, T, c, strict=strict) as m:
+            m.set_params(lam, inv_s=inv_s)
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf(x=False, e=False)
+        _check_solve(act, inf, ref, cost_exact=strict, tag=f"params strict={strict}")
+
+
+def test_ref_compat_reproduces_a3_coverage_defect(gpu):
+    """with ref_compat the update sums only the samples the reference's
+    update_act covers for act_dim 3, while beta and nabla still use all K."""
+    A, K, T = 3, 3000, 20
+    c = ol.make_case(A, K, T, seed=77)
+    full = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    cov = 2048
+    wts = full["weights"].copy()
+    wts[cov:] = 0
+    U_upd = ol.update(c["U"], wts, c["E"], f64=True)
+    with _model(gpu, A, K, T, c) as m:
+        m.set_ref_compat(True)
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf(x=False, e=False)
+    np.testing.assert_allclose(inf["nabla"], full["nabla"], rtol=2e-6)
+    scale = max(float(np.abs(U_upd).max()), SIGMA)
+    assert np.abs(act - U_upd[0]).max() <= 1e-5 * scale
+    assert np.abs(inf["u"][:-1] - U_upd[1:]).max() <= 1e-5 * scale
+    # and it does differ from the correct update
+    assert np.abs(inf["u"] - full["U"]).max() > 1e-6
+
+
+def test_sharded_engines_equal_single_engine(gpu):
+    """Two shard engines on one GPU (k offsets 0 and K/2) + gather + finish == one engine."""
+    import torch
+    A, K, T = 3, 4000, 200
+    c = ol.make_case(A, K, T, seed=88)
+    from mppi_gpu_amd import PointMassModel
+    with _model(gpu, A, K, T, c) as m:
+        m.set_seed(5)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        act1 = m.get_act()
+        U1 = m.get_u()
+        E1 = m.get_inf(x=False, u=False, cost=False, beta=False, nabla=False, weight=False)["e"]
+        act1b = m.get_act()
+    shards = []
+    half = K // 2 + 100                      # uneven split
+    for off, n in ((0, half), (half, K - half)):
+        s = PointMassModel(n, T, float(c["dt"]), 2 * A, A, k_offset=off)
+        s.set_seed(5)
+        s.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        shards.append(s)
+    L = shards[0].partial_len()
+    assert L == T * A + 2
+    for it in range(2):
+        gathered = torch.zeros(2, L, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        for i, s in enumerate(shards):
+            s.solve_local_async(gathered[i].data_ptr())
+            s.sync_act()
+        acts = []
+        for s in shards:
+            s.solve_finish_async(gathered.data_ptr(), 2)
+            acts.append(s.sync_act())
+        assert np.array_equal(acts[0], acts[1]), "ranks must agree bit for bit"
+        if it == 0:
+            E = np.concatenate([s.get_inf(x=False, u=False, cost=False, beta=False, nabla=False,
+                                          weight=False)["e"] for s in shards])
+            assert np.array_equal(E, E1), "noise must not depend on the sharding"
+            scale = max(float(np.abs(U1).max()), SIGMA)
+            assert np.abs(acts[0] - act1).max() <= 2e-6 * scale
+            assert np.abs(shards[0].get_u() - U1).max() <= 2e-6 * scale
+            assert np.array_equal(shards[0].get_u(), shards[1].get_u())
+        else:
+            assert np.abs(acts[0] - act1b).max() <= 1e-5 * SIGMA * 4
+    for s in shards:
+        s.close()
+
+
+# ---- BASELINE.json full sizes: size-independent properties + oracle on the device's noise ----
+
+FULL = [(2, 10_000, 200), (3, 100_000, 200)]
+
+
+@pytest.mark.parametrize("A,K,T", FULL)
+def test_full_size_parity_and_properties(gpu, A, K, T):
+    c = ol.make_case(A, 1, T, seed=300 + A, u_scale=0.02)
+    with _model(gpu, A, K, T, c) as m:
+        m.set_seed(42)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        act = m.get_act()
+        inf = m.get_inf(x=False)
+        geo = m.geometry()
+    # (1) the oracle, run on the very noise the device drew, reproduces the solve
+    ref = ol.solve(c["x0"], c["U"], inf["e"], c["goal"], c["w"], c["dt"])
+    _check_solve(act, inf, ref, cost_exact=False, tag=f"full A{A} K{K} {geo}")
+    # (2) weights are a probability vector
+    assert np.isclose(inf["weight"].astype(np.float64).sum(), 1.0, atol=2e-5)
+    assert inf["weight"].min() >= 0 and np.isclose(inf["weight"].max(), 1.0 / inf["nabla"], rtol=1e-5)
+    # (3) noise statistics of the whole batch
+    z = inf["e"] / np.float32(SIGMA)
+    assert abs(z.mean()) < 5e-4 and abs(z.std() - 1) < 5e-4
+    # (4) determinism: same seed -> identical bits, different seed -> different action
+    with _model(gpu, A, K, T, c) as m2:
+        m2.set_seed(42)
+        m2.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        act2 = m2.get_act()
+        U2 = m2.get_u()
+        m2.set_seed(43)
+        m2.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        act3 = m2.get_act()
+    assert np.array_equal(act, act2) and np.array_equal(U2, inf["u"])
+    assert not np.array_equal(act, act3)

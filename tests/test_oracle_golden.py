@@ -1,0 +1,175 @@
+"""CPU tests of the oracle itself: pinned against the reference's own code and test vectors.
+
+  - cost_ref.npz  : outputs of the REFERENCE's src/cost.cu (compiled unmodified, oracle/_ref)
+  - src/test.cu   : the reference's known-answer generators (update ramps :77-105, exp :11-59)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+
+
+def test_cost_matches_reference_cost_cu_bit_for_bit():
+    g = np.load(os.path.join(GOLDEN, "cost_ref.npz"))
+    n = len(g["A"])
+    assert n >= 500
+    for i in range(n):
+        A = int(g["A"][i]); S = 2 * A
+        sc = ol.step_cost(g["x"][i][:S], g["u"][i][:A], g["e"][i][:A], g["w"][i][:S],
+                          g["goal"][i][:S], g["lam"][i], g["inv_s"][i][:A])
+        fc = ol.final_cost(g["x"][i][:S], g["w"][i][:S], g["goal"][i][:S])
+        assert sc.tobytes() == g["step_cost"][i].tobytes(), i
+        assert fc.tobytes() == g["final_cost"][i].tobytes(), i
+
+
+@pytest.mark.skipif(ol.ref_cost_lib() is None and not os.path.isdir("/root/reference/src"),
+                    reason="reference sources absent (GPU box): live reference build not possible")
+def test_cost_matches_live_reference_build():
+    """Where /root/reference exists, call the freshly compiled reference Cost directly."""
+    import ctypes as C
+    ol.build()
+    r = ol.ref_cost_lib()
+    assert r is not None
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        A = int(rng.integers(1, 5)); S = 2 * A
+        x, u, e, w, g, inv = [np.ascontiguousarray(rng.standard_normal(m), np.float32)
+                              for m in (S, A, A, S, S, A)]
+        lam = np.float32(rng.uniform(0.3, 2))
+        p = lambda a: a.ctypes.data_as(ol.fp)  # noqa: E731
+        ref = np.float32(r.ref_step_cost(p(x), p(u), p(e), p(w), p(g), C.c_float(lam), p(inv), S, A))
+        assert ol.step_cost(x, u, e, w, g, lam, inv).tobytes() == ref.tobytes()
+        ref = np.float32(r.ref_final_cost(p(x), p(w), p(g), S))
+        assert ol.final_cost(x, w, g).tobytes() == ref.tobytes()
+
+
+def _kat_inputs(n, t, a):
+    import ctypes as C
+    u = np.empty(t * a, np.float32); w = np.empty(n, np.float32); e = np.empty(n * t * a, np.float32)
+    ol.oracle().orc_kat_update_inputs(ol._p(u), ol._p(w), ol._p(e), n, t, a)
+    return u, w, e
+
+
+def test_update_known_answer_of_reference_test_cu():
+    """reference src/test.cu:77-105: ramps e=0.25*idx, w=0.5*k, u=0.75*idx; expectation
+    u[j,a] += sum_k w[k]*e[k,j,a] in float, k outermost (update_act_cpu)."""
+    a = 2
+    for n in (1, 2, 7, 33, 59):
+        for t in (1, 5, 50, 99):
+            u, w, e = _kat_inputs(n, t, a)
+            # generator restated independently in numpy (float32 of a double product)
+            idx = np.arange(n * t * a, dtype=np.float64)
+            assert np.array_equal(e, (0.25 * idx).astype(np.float32))
+            assert np.array_equal(w, (0.5 * np.arange(n)).astype(np.float32))
+            assert np.array_equal(u, (0.75 * np.arange(t * a)).astype(np.float32))
+            got = ol.update(u.reshape(t, a), w, e.reshape(n, t, a))
+            exp = u.copy()
+            E = e.reshape(n, t * a)
+            for k in range(n):                       # float accumulation, k outermost
+                exp = (exp + w[k] * E[k]).astype(np.float32)
+            assert np.array_equal(got.reshape(-1), exp), (n, t)
+            # TOL of the reference (include/point_mass.hpp:16) against the f64 sum where exact
+            got64 = ol.update(u.reshape(t, a), w, e.reshape(n, t, a), f64=True).reshape(-1)
+            ref64 = u.astype(np.float64) + (w.astype(np.float64)[:, None] * E.astype(np.float64)).sum(0)
+            assert np.allclose(got64, ref64.astype(np.float32), rtol=1e-6, atol=0)
+
+
+def test_exp_known_answer_of_reference_test_cu():
+    """reference src/test.cu:11-59: cost=i, lambda=1, beta=0.25 -> exp(-lambda*(c-beta)), TOL 1e-6"""
+    import ctypes as C
+    for n in (1, 17, 59):
+        cost = np.arange(n, dtype=np.float32)
+        out = np.empty(n, np.float32)
+        ol.oracle().orc_exp(ol._p(cost), C.c_float(1.0), C.c_float(0.25), ol._p(out), n)
+        for i in range(n):
+            exp = ol.oracle().orc_kat_exp_expected(C.c_float(cost[i]), C.c_float(1.0), C.c_float(0.25))
+            assert abs(exp - out[i]) < 1e-6
+            assert abs(np.exp(-1.0 * (float(cost[i]) - 0.25)) - out[i]) < 1e-6
+
+
+def test_rollout_matches_closed_form_double_integrator():
+    """No noise, constant acceleration a: v_t = v0 + a t dt, p_t = p0 + v0 t dt + a (t dt)^2 / 2
+    (exact for this integrator because B0 = dt^2/2)."""
+    A, T, dt = 2, 40, np.float32(0.1)
+    x0 = np.array([0.3, -0.2, 0.05, 0.1], np.float32)
+    acc = np.array([0.4, -0.25], np.float32)
+    U = np.tile(acc, (T, 1)).astype(np.float32)
+    E = np.zeros((1, T, A), np.float32)
+    cost, X = ol.rollout(x0, U, E, np.zeros(4), np.ones(4), dt, want_X=True)
+    t = np.arange(T + 1, dtype=np.float64)[:, None] * float(dt)
+    p = x0[:2].astype(np.float64) + x0[2:].astype(np.float64) * t + 0.5 * acc.astype(np.float64) * t * t
+    v = x0[2:].astype(np.float64) + acc.astype(np.float64) * t
+    assert np.allclose(X[0, :, :2], p, rtol=0, atol=2e-5)
+    assert np.allclose(X[0, :, 2:], v, rtol=0, atol=2e-5)
+    # cost = sum of stage costs on x_1..x_T plus terminal on x_T (x_T counted twice)
+    d = np.concatenate([p, v], 1)
+    stage = (d[1:] ** 2).sum()
+    assert np.isclose(cost[0], stage + (d[-1] ** 2).sum(), rtol=1e-5)
+
+
+def test_nabla_tree_agrees_with_f64_sum():
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for K in (1, 255, 256, 511, 512, 513, 3000, 10000, 131073):
+        ex = rng.uniform(0, 1, K).astype(np.float32)
+        t = np.float32(ol.oracle().orc_nabla_tree(ol._p(ex), K))
+        s = np.float32(ol.oracle().orc_nabla(ol._p(ex), K))
+        assert np.isclose(t, s, rtol=2e-6), K
+        assert np.isclose(s, ex.astype(np.float64).sum(), rtol=1e-7)
+
+
+def test_solve_fixtures_are_reproduced_by_the_oracle():
+    """The committed solve_*.npz were written by this oracle: it must still reproduce them
+    bit for bit (guards the oracle against silent edits)."""
+    names = sorted(f for f in os.listdir(GOLDEN) if f.startswith("solve_") and f.endswith(".npz"))
+    assert len(names) >= 7
+    for f in names:
+        g = np.load(os.path.join(GOLDEN, f))
+        out = ol.solve(g["x0"], g["U"], g["E"], g["goal"], g["w"], g["dt"], f64_update=True)
+        assert np.array_equal(out["cost"], g["cost"]), f
+        assert out["beta"] == g["beta"] and out["nabla"] == g["nabla"], f
+        assert np.array_equal(out["weights"], g["weights"]), f
+        assert np.array_equal(out["U"], g["U_next"]), f
+        assert np.array_equal(out["next_act"], g["next_act"]), f
+        assert np.isclose(out["weights"].astype(np.float64).sum(), 1.0, atol=1e-5)
+
+
+def test_solve_semantics_shift_and_action():
+    c = ol.make_case(2, 50, 12, 1)
+    out = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    full = ol.update(c["U"], out["weights"], c["E"], f64=True)      # updated, unshifted
+    assert np.array_equal(out["next_act"], full[0])
+    assert np.array_equal(out["U"][:-1], full[1:])
+    assert np.array_equal(out["U"][-1], full[-1])                   # last step repeated
+
+
+def test_reference_update_coverage_defect_formula():
+    """for act_dim 3 the reference sums only min(K, 512*(K/768+1)) samples."""
+    cov = ol.oracle().orc_ref_update_coverage_a3
+    assert cov(3000) == 2048 and cov(100000) == 67072 and cov(100) == 100
+
+
+def test_noise_oracle_stream_properties():
+    """Noise stream stated over rocRAND's public host API: layout independence, determinism,
+    distribution (the reference's cuRAND stream cannot be reproduced)."""
+    E1 = ol.noise(0, 0, 0, 64, 200, 3, [0.025] * 3)
+    E2 = ol.noise(0, 0, 0, 64, 200, 3, [0.025] * 3)
+    assert np.array_equal(E1, E2)
+    # shard invariance: samples 32..63 generated with an offset equal the tail of the full batch
+    E3 = ol.noise(0, 0, 32, 32, 200, 3, [0.025] * 3)
+    assert np.array_equal(E1[32:], E3)
+    # different solves / seeds give different noise
+    assert not np.array_equal(E1, ol.noise(0, 1, 0, 64, 200, 3, [0.025] * 3))
+    assert not np.array_equal(E1, ol.noise(7, 0, 0, 64, 200, 3, [0.025] * 3))
+    big = ol.noise(1, 0, 0, 2000, 200, 2, [0.025, 0.05])
+    assert abs(big[..., 0].mean()) < 2e-4 and abs(big[..., 0].std() - 0.025) < 2e-4
+    assert abs(big[..., 1].std() - 0.05) < 4e-4
+    # per-axis, per-step independence (lag-1 correlation ~ 0)
+    z = big[..., 0]
+    assert abs(np.corrcoef(z[:, :-1].ravel(), z[:, 1:].ravel())[0, 1]) < 0.01
+    # raw Philox words are the Random123 known answer for an all-zero counter and key
+    w0 = ol.noise_block_u32(0, 0, 0)
+    assert list(w0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
