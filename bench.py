@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="record HIP events around the kernels of every n-th timed solve")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,12 +128,13 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        m.sync_act()          # the engine's own stream (same HIP runtime as torch's: see _capi)
 
     for _ in range(args.warmup):
         step()
     fence()
     if not args.no_events:
-        m.set_profiling(True)
+        m.set_profiling(max(1, args.event_every))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

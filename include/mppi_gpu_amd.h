@@ -127,8 +127,10 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
 
 /* ---- measurement ------------------------------------------------------------------- */
 
-/* When on, every solve records HIP events around its kernels on the launch stream. */
-int mppi_set_profiling(mppi_engine* e, int on);
+/* every > 0: each `every`-th solve records HIP events around its kernels on the launch stream
+ * (an event pair costs a few microseconds of stream time, so sparse sampling keeps the timed
+ * region honest); 0 switches recording off. */
+int mppi_set_profiling(mppi_engine* e, int every);
 /* Average duration in ms of kernel `which` (0 = rollout, 1 = combine) over the solves since
  * profiling was switched on; *n_out = number of launches averaged. Synchronises. */
 int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);

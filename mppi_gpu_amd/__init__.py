@@ -188,8 +188,9 @@ class PointMassModel:
                                                 C.c_void_p(stream or 0)))
 
     # -- measurement ------------------------------------------------------------------------
-    def set_profiling(self, on):
-        check(self._lib.mppi_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, every):
+        """every > 0: record HIP events around the kernels of each `every`-th solve."""
+        check(self._lib.mppi_set_profiling(self._h, int(every)))
 
     def kernel_ms(self, which):
         avg = C.c_double()

@@ -56,6 +56,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64.so with the SAME soname as /opt/rocm's.  Whichever is
+    # loaded first serves every later DT_NEEDED of that soname, so torch must come first: then
+    # this library, torch's allocator/streams and RCCL all share ONE HIP runtime (stream and
+    # device-pointer handles are interchangeable).  The other order leaves two runtimes in the
+    # process and torch cannot see the GPU.  Without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

@@ -98,7 +98,9 @@ struct mppi_engine {
     hipStream_t last_stream = nullptr;   // stream of the most recent enqueue
 
     // profiling
-    bool prof = false;
+    int prof = 0;                   // 0 = off, n = record every n-th solve
+    bool prof_now = false;
+    unsigned long long prof_count = 0;
     std::vector<hipEvent_t> ev;     // 3 per solve: before rollout, after rollout, after combine
     size_t ev_used = 0;
 };
@@ -231,7 +233,7 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
 
 int prof_event(mppi_engine_t* e, hipStream_t st)
 {
-    if (!e->prof) return MPPI_OK;
+    if (!e->prof_now) return MPPI_OK;
     if (e->ev_used == e->ev.size()) {
         if (e->ev.size() >= 3 * 8192) return MPPI_OK;   // stop recording, keep running
         hipEvent_t ne;
@@ -255,6 +257,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
     }
     mppi::RolloutArgs ra;
     fill_rollout_args(e, ra);
+    e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
     if ((rc = prof_event(e, st))) return rc;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st));
@@ -607,7 +610,9 @@ int mppi_set_profiling(mppi_engine* e, int on)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->prof = on != 0;
+    e->prof = on > 0 ? on : 0;
+    e->prof_now = false;
+    e->prof_count = 0;
     e->ev_used = 0;
     return MPPI_OK;
 }

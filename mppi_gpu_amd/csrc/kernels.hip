@@ -548,8 +548,20 @@ k_combine(const CombineArgs a)
     const int n = blockIdx.x * kCombineCols + lane;
     float acc = 0.0f;
     if (n < a.TA) {
-        for (int p = wave; p < a.n_parts; p += 16)
-            acc = fmaf(r_lds[p], a.N[(size_t)p * a.N_stride + n], acc);
+        // 8 independent row loads in flight per lane; the accumulation order stays fixed
+        for (int p0 = wave; p0 < a.n_parts; p0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = p0 + 16 * j;
+                v[j] = (p < a.n_parts) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = p0 + 16 * j;
+                if (p < a.n_parts) acc = fmaf(r_lds[p], v[j], acc);
+            }
+        }
     }
     red[wave * kCombineCols + lane] = acc;
     __syncthreads();
