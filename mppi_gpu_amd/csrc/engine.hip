@@ -56,7 +56,7 @@ int ilog2(int x)
 
 struct mppi_engine {
     // problem
-    int K = 0, T = 0, S = 0, A = 0, TA = 0, SPB = 0, W = 0, NBT = 0;
+    int K = 0, T = 0, S = 0, A = 0, TA = 0, SG = 0, BPG = 0, NGT = 0, NBT = 0;
     long long k_offset = 0;
     bool sharded = false;
     float dt = 0.f, B0 = 0.f, lambda = 1.f;
@@ -72,7 +72,8 @@ struct mppi_engine {
     // geometry
     int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
     bool geom_ok = false;
-    int C = 1, logC = 0, nq = 0, NQt = 0, n_tileblk = 0, grid = 0, strict = 0;
+    int C = 1, logC = 0, ng = 0, nq = 0, NGt = 0, L = 0, c_last = 0, n_last = 0, NBTp = 0;
+    int n_tileblk = 0, grid = 0, strict = 0;
     // geometry the stored noise / partials belong to
     int last_C = 1, last_nq = 0;
     unsigned long long last_idx = 0;
@@ -125,14 +126,14 @@ int ensure_scratch(mppi_engine_t* e, size_t floats)
 int ensure_geometry(mppi_engine_t* e)
 {
     if (e->geom_ok) return MPPI_OK;
-    const int NBT = e->NBT;
-    int C, nq, NQt = 0, strict = e->user_strict ? 1 : 0;
+    const int NGT = e->NGT;          // groups per trajectory
+    int C, ng, NGt = 0, strict = e->user_strict ? 1 : 0;
     if (strict) {
         C = 1;
-        nq = NBT;
+        ng = NGT;
     } else {
-        const int nq_max = (e->A == 3) ? 25 : 20;
-        const int Cmin = next_pow2((NBT + nq_max - 1) / nq_max);
+        const int ng_max = mppi::rollout_max_groups(e->A);
+        const int Cmin = next_pow2((NGT + ng_max - 1) / ng_max);
         if (Cmin > 64)
             return fail(MPPI_EINVAL, "horizon too long for the register-resident kernel: %d steps",
                         e->T);
@@ -142,15 +143,20 @@ int ensure_geometry(mppi_engine_t* e)
                 return fail(MPPI_EINVAL, "chunks must be a power of two in [%d, 64], got %d", Cmin,
                             C);
         } else {
-            // fill the chip: aim for >= 2048 wavefronts, keep >= 4 Philox blocks per lane
+            // fill the chip: aim for >= 2048 wavefronts while a lane keeps >= 4 groups
             C = Cmin;
-            while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NBT + 2 * C - 1) / (2 * C) >= 4)
+            while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NGT + 2 * C - 1) / (2 * C) >= 4)
                 C <<= 1;
         }
-        nq = (NBT + C - 1) / C;
-        NQt = mppi::rollout_pick_nq_template(e->A, nq);
-        if (!NQt) return fail(MPPI_EINVAL, "no kernel for %d blocks per lane", nq);
+        ng = (NGT + C - 1) / C;
+        NGt = mppi::rollout_pick_ng_template(e->A, ng);
+        if (!NGt) return fail(MPPI_EINVAL, "no kernel for %d groups per lane", ng);
     }
+    const int nq = ng * e->BPG;
+    const int L = ng * e->SG;
+    const int c_last = (e->T - 1) / L;
+    const int n_last = e->T - c_last * L;
+    const int NBTp = (C * nq > e->NBT) ? C * nq : e->NBT;
     const long long lanes = (long long)e->K * C;
     const long long ntb = (lanes + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
     if (ntb > 0x7fffffffLL) return fail(MPPI_EINVAL, "too many samples");
@@ -158,12 +164,12 @@ int ensure_geometry(mppi_engine_t* e)
     if (max_blocks > mppi::kMaxParts) max_blocks = mppi::kMaxParts;
     const int grid = (int)(ntb < max_blocks ? ntb : max_blocks);
 
-    const size_t lds = mppi::rollout_lds_bytes(NBT, C * nq * e->W);
+    const size_t lds = mppi::rollout_lds_bytes(NBTp, C * nq * 4);
     if (lds > 64 * 1024)
         return fail(MPPI_EINVAL, "LDS need %zu B exceeds 64 KiB (T=%d A=%d C=%d)", lds, e->T, e->A,
                     C);
 
-    const size_t need = (size_t)ntb * 4 * nq * 64 * e->W;
+    const size_t need = (size_t)ntb * 4 * nq * 64 * 4;
     if (need > e->eint_floats) {
         if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
         e->d_Eint = nullptr;
@@ -185,8 +191,13 @@ int ensure_geometry(mppi_engine_t* e)
     }
     e->C = C;
     e->logC = ilog2(C);
+    e->ng = ng;
     e->nq = nq;
-    e->NQt = NQt;
+    e->NGt = NGt;
+    e->L = L;
+    e->c_last = c_last;
+    e->n_last = n_last;
+    e->NBTp = NBTp;
     e->strict = strict;
     e->n_tileblk = (int)ntb;
     e->grid = grid;
@@ -219,9 +230,14 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.T = e->T;
     a.TA = e->TA;
     a.NBT = e->NBT;
+    a.NBTp = e->NBTp;
     a.C = e->C;
     a.logC = e->logC;
+    a.ng = e->ng;
     a.nq = e->nq;
+    a.L = e->L;
+    a.c_last = e->c_last;
+    a.n_last = e->n_last;
     a.n_tileblk = e->n_tileblk;
     a.dt = e->dt;
     a.B0 = e->B0;
@@ -262,7 +278,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st));
     else
-        HIPCHK(mppi::launch_rollout_fused(e->A, e->NQt, !e->injected, e->grid, ra, st));
+        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, !e->injected, e->grid, ra, st));
     if ((rc = prof_event(e, st))) return rc;
     e->last_C = e->C;
     e->last_nq = e->nq;
@@ -310,8 +326,10 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
 
     mppi_engine* e = new mppi_engine();
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
-    e->SPB = 4 / A; e->W = e->SPB * A;
-    e->NBT = (T + e->SPB - 1) / e->SPB;
+    e->SG = mppi::rollout_group_steps(A);
+    e->BPG = mppi::rollout_group_blocks(A);
+    e->NGT = (T + e->SG - 1) / e->SG;
+    e->NBT = (e->TA + 3) / 4;
     e->k_offset = k_offset;
     e->sharded = sharded;
     e->dt = dt;

@@ -4,10 +4,11 @@
 //   DevState      : x0[8] (set_x writes it with one small H2D copy) and the observables
 //                   beta / nabla of the last solve.
 //   U             : 2 x [T*A] floats, double-buffered by solve_idx parity (in = idx&1).
-//   Eint          : noise in TILE layout: float[tiles][nq][64][W]; a tile is one wavefront's
+//   Eint          : noise in TILE layout: float4[tiles][nq][64]; a tile is one wavefront's
 //                   64 lanes = 64/C trajectories x C time-chunks, lane = (k%(64/C))*C + c;
-//                   W = 4 (A=1,2,4) or 3 (A=3) floats = the normals of one Philox block.
-//                   Every store and load of it is a full-wave contiguous 1 KiB / 768 B access.
+//                   one float4 = the 4 normals of one Philox block (flat index n = t*A + a,
+//                   block n/4).  Every store and load of it is one full-wave contiguous
+//                   1 KiB global_store/load_dwordx4.
 //   cost          : [K] floats.
 //   part_m/part_s : [grid] per-block running min and exp-sum (relative to that min).
 //   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
@@ -39,10 +40,15 @@ struct RolloutArgs {
     int K;                 // local samples
     int T;
     int TA;                // T*A
-    int NBT;               // Philox blocks per sample per solve = ceil(T/spb)
+    int NBT;               // Philox blocks per sample per solve = ceil(T*A/4)
+    int NBTp;              // blocks of U staged in LDS = max(NBT, C*nq)
     int C;                 // lanes per trajectory (power of two)
     int logC;
-    int nq;                // Philox blocks per lane (chunk length in blocks)
+    int ng;                // groups per lane (group = smallest run of whole steps AND blocks)
+    int nq;                // Philox blocks per lane = ng * blocks-per-group
+    int L;                 // steps per full chunk = ng * steps-per-group
+    int c_last;            // chunk holding step T-1; chunks beyond are empty
+    int n_last;            // valid steps in chunk c_last (1..L)
     int n_tileblk;         // number of 256-lane tile groups = ceil(K*C/256)
     float dt;
     float B0;              // (float)(dt*dt/2.0)
@@ -79,11 +85,15 @@ constexpr int kCombineThreads = 1024;
 constexpr int kCombineCols = 64;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 
-// Supported register-resident chunk lengths (template NQ); pick the smallest >= nq.
-int rollout_pick_nq_template(int A, int nq);     // returns 0 if nq is too large
-size_t rollout_lds_bytes(int NBT, int TAp);
+// Group geometry by action dimension and the instantiated register-resident chunk lengths
+// (template NG = groups per lane); pick returns the smallest instantiated NG >= ng, 0 if none.
+int rollout_group_steps(int A);
+int rollout_group_blocks(int A);
+int rollout_max_groups(int A);
+int rollout_pick_ng_template(int A, int ng);
+size_t rollout_lds_bytes(int NBTp, int TAp);
 
-hipError_t launch_rollout_fused(int A, int NQt, bool sample, int grid, const RolloutArgs& a,
+hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
                                 hipStream_t st);
 hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
                                  hipStream_t st);

@@ -173,3 +173,17 @@ def test_noise_oracle_stream_properties():
     # raw Philox words are the Random123 known answer for an all-zero counter and key
     w0 = ol.noise_block_u32(0, 0, 0)
     assert list(w0) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+def test_hw_box_muller_restatement_agrees_with_rocrand_normal4():
+    """The engine's Box-Muller (log2 / revolutions form, as restated on the host) gives the same
+    normals as rocRAND's own rocrand_normal4 on the same Philox block, to float rounding."""
+    import ctypes as C
+    nl = ol.noise_lib()
+    worst = 0.0
+    for k in range(0, 4000, 7):
+        out = (C.c_float * 4)()
+        nl.orc_noise_block_rocrand_normal(C.c_ulonglong(99), C.c_ulonglong(k), C.c_ulonglong(3), out)
+        mine = ol.noise(99, 0, k, 1, 100, 1, [1.0])[0, 12:16, 0]      # block 3 = normals 12..15
+        worst = max(worst, float(np.abs(np.array(list(out), np.float32) - mine).max()))
+    assert worst < 2e-6, worst
