@@ -1,0 +1,275 @@
+// device_common.hpp -- device-side building blocks shared by the rollout kernels:
+// counter-addressed rocRAND Philox, the hardware Box-Muller, DPP / lane-swap reductions, the
+// reference's step and cost arithmetic, and the per-block running (min, exp-sum, sums) fold.
+#pragma once
+#include "kernels.hpp"
+
+#include <rocrand/rocrand_kernel.h>
+
+namespace mppi {
+
+
+// ------------------------------------------------------------------------------------------
+// rocRAND Philox4x32-10, addressed by counter.  ten_rounds() is a protected member of
+// rocRAND's engine; deriving from it lets a lane evaluate block (counter, key) directly
+// -- random access in (sample, time) with no stored generator state.  Identical words to
+// rocrand_init(seed, subsequence = k, offset = 4*block) + rocrand4() (tests check this).
+// ------------------------------------------------------------------------------------------
+struct PhiloxAt : public rocrand_device::philox4x32_10_engine {
+    __device__ __forceinline__ static uint4 block(unsigned long long blk, unsigned long long k,
+                                                  unsigned long long seed)
+    {
+        PhiloxAt eng;
+        uint4 ctr;
+        ctr.x = static_cast<unsigned int>(blk);
+        ctr.y = static_cast<unsigned int>(blk >> 32);
+        ctr.z = static_cast<unsigned int>(k);
+        ctr.w = static_cast<unsigned int>(k >> 32);
+        uint2 key;
+        key.x = static_cast<unsigned int>(seed);
+        key.y = static_cast<unsigned int>(seed >> 32);
+        return eng.ten_rounds(ctr, key);
+    }
+};
+
+// Box-Muller on the CDNA4 transcendental units.  Same uniforms as rocRAND's box_muller
+// (rocrand_normal.h: u = 2^-32 + x*2^-32), with
+//   radius  sqrt(-2 ln u)   = v_sqrt_f32( (-2 ln 2) * v_log_f32(u) )         (v_log is log2)
+//   angle   2 pi * theta    : v_sin_f32 / v_cos_f32 take theta in REVOLUTIONS, so the
+//                             2 pi multiply (and the 1/2pi inside __sincosf) disappears.
+// Agrees with rocRAND's host box_muller to ~1e-6 absolute per normal (tests).
+__device__ __forceinline__ void box_muller_hw(unsigned int x, unsigned int y, float& z0, float& z1)
+{
+    const float kInv = 2.3283064e-10f;                       // 2^-32
+    const float u = kInv + (float)x * kInv;                  // (0, 1]
+    const float th = kInv + (float)y * kInv;                 // (0, 1] revolutions
+    const float r2 = -1.3862943611198906f * __builtin_amdgcn_logf(u);
+    const float s = __builtin_amdgcn_sqrtf(r2);
+    z0 = __builtin_amdgcn_sinf(th) * s;
+    z1 = __builtin_amdgcn_cosf(th) * s;
+}
+
+// Geometry by action dimension.  The noise of one sample and one solve is the flat sequence
+// n = t*A + a; Philox block b holds normals 4b..4b+3.  A GROUP is the smallest run of whole
+// steps that is also a run of whole blocks.
+template <int A>
+struct Dim {
+    static_assert(A >= 1 && A <= 4, "act_dim 1..4");
+    static constexpr int SG = (A == 1) ? 4 : (A == 2) ? 2 : (A == 3) ? 4 : 1;   // steps / group
+    static constexpr int BPG = SG * A / 4;                                       // blocks / group
+};
+
+// ---- cross-lane primitives: DPP and lane-swap instructions, no LDS ------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+constexpr int kQuadXor1 = 0xB1;      // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;      // quad_perm [2,3,0,1]
+constexpr int kHalfMirror = 0x141;   // lane i <-> 7-i within 8
+constexpr int kRowMirror = 0x140;    // lane i <-> 15-i within 16
+#define MPPI_ROW_ROR(n) (0x120 + (n))
+#define MPPI_ROW_SHR(n) (0x110 + (n))
+
+__device__ __forceinline__ void swap16(float x, float& a, float& b)
+{   // a + b = x[row r] + x[row r^1]   (v_permlane16_swap_b32)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(float x, float& a, float& b)
+{   // a + b = x[lane] + x[lane ^ 32]  (v_permlane32_swap_b32)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// sum over the aligned group of 2^LOGC consecutive lanes; every lane of the group ends with the
+// same bits
+template <int LOGC>
+__device__ __forceinline__ float group_sum(float x)
+{
+    if constexpr (LOGC >= 1) x += dpp<kQuadXor1>(x);
+    if constexpr (LOGC >= 2) x += dpp<kQuadXor2>(x);
+    if constexpr (LOGC >= 3) x += dpp<kHalfMirror>(x);
+    if constexpr (LOGC >= 4) x += dpp<kRowMirror>(x);
+    if constexpr (LOGC >= 5) { float a, b; swap16(x, a, b); x = a + b; }
+    if constexpr (LOGC >= 6) { float a, b; swap32(x, a, b); x = a + b; }
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) { return group_sum<6>(x); }
+__device__ __forceinline__ float wave_min(float x)
+{
+    x = fminf(x, dpp<kQuadXor1>(x));
+    x = fminf(x, dpp<kQuadXor2>(x));
+    x = fminf(x, dpp<kHalfMirror>(x));
+    x = fminf(x, dpp<kRowMirror>(x));
+    { float a, b; swap16(x, a, b); x = fminf(a, b); }
+    { float a, b; swap32(x, a, b); x = fminf(a, b); }
+    return x;
+}
+
+// sum over the lanes {l : l % 2^LOGC == lane % 2^LOGC} of the wave; rotation based, so the
+// association differs per lane -- callers read fixed lanes only
+template <int LOGC>
+__device__ __forceinline__ float strided_sum(float x)
+{
+    if constexpr (LOGC <= 0) x += dpp<MPPI_ROW_ROR(1)>(x);
+    if constexpr (LOGC <= 1) x += dpp<MPPI_ROW_ROR(2)>(x);
+    if constexpr (LOGC <= 2) x += dpp<MPPI_ROW_ROR(4)>(x);
+    if constexpr (LOGC <= 3) x += dpp<MPPI_ROW_ROR(8)>(x);
+    if constexpr (LOGC <= 4) { float a, b; swap16(x, a, b); x = a + b; }
+    if constexpr (LOGC <= 5) { float a, b; swap32(x, a, b); x = a + b; }
+    return x;
+}
+
+// value of lane (lane - D) within the aligned group of 2^LOGC lanes; caller masks c < D.
+// Groups of <= 16 lanes lie inside one DPP row (row_shr); wider groups cross rows and go
+// through ds_bpermute.
+template <int D, int LOGC>
+__device__ __forceinline__ float lane_up(float x)
+{
+    if constexpr (D < 16 && LOGC <= 4) return dpp<MPPI_ROW_SHR(D)>(x);
+    else return __shfl_up(x, D, 1 << LOGC);
+}
+template <int D, int LOGC>
+__device__ __forceinline__ int lane_up_i(int x)
+{
+    if constexpr (D < 16 && LOGC <= 4) return dppi<MPPI_ROW_SHR(D)>(x);
+    else return __shfl_up(x, D, 1 << LOGC);
+}
+
+// One Euler step of the double integrator, reference src/point_mass_gpu.cu:97-106 with
+// x_gain = {1, dt, 0, 1}, u_gain = {B0, dt}: the multiplications by 1 and 0 are exact and
+// dropped; every remaining product and sum rounds separately, left to right.
+template <int A>
+__device__ __forceinline__ void lti_step(float (&p)[A], float (&v)[A], const float* u,
+                                         const float* e, float dt, float B0)
+{
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float a = u[i] + e[i];
+        const float pn = (p[i] + dt * v[i]) + B0 * a;
+        const float vn = v[i] + dt * a;
+        p[i] = pn;
+        v[i] = vn;
+    }
+}
+
+// Cost::step_cost, reference src/cost.cu:42-55, on the state AFTER the step.
+template <int A>
+__device__ __forceinline__ float stage_cost(const float (&p)[A], const float (&v)[A],
+                                            const float* u, const float* e,
+                                            const RolloutArgs& g)
+{
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) r += (u[i] * g.inv_s[i]) * e[i];
+    r *= g.lambda;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = p[i] - g.goal[i];
+        r += (d * g.w[i]) * d;
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = v[i] - g.goal[A + i];
+        r += (d * g.w[A + i]) * d;
+    }
+    return r;
+}
+
+// Cost::final_cost, reference src/cost.cu:57-64.
+template <int A>
+__device__ __forceinline__ float final_cost(const float (&p)[A], const float (&v)[A],
+                                            const RolloutArgs& g)
+{
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = p[i] - g.goal[i];
+        r += (d * g.w[i]) * d;
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = v[i] - g.goal[A + i];
+        r += (d * g.w[A + i]) * d;
+    }
+    return r;
+}
+
+// Draw the 4 normals of Philox block `blk` of global sample kglob; normal i of the block is
+// flat index n = 4*(blk % NBT) + i, i.e. axis (n % A): `a0` = axis of element 0.
+template <int A>
+__device__ __forceinline__ void draw_block(unsigned long long blk, unsigned long long kglob,
+                                           int a0, const RolloutArgs& g, float* e)
+{
+    const uint4 r = PhiloxAt::block(blk, kglob, g.seed);
+    float z[4];
+    box_muller_hw(r.x, r.y, z[0], z[1]);
+    box_muller_hw(r.z, r.w, z[2], z[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = g.sigma[(a0 + i) % A] * z[i];
+}
+
+struct RunState {
+    float M;      // running minimum of the block
+    float S;      // running sum of exp(-(c-M)/lambda)
+};
+
+__device__ __forceinline__ float tile_min(float cost_or_inf, float* misc, int wave, int lane)
+{
+    const float m = wave_min(cost_or_inf);
+    if (lane == 0) misc[wave] = m;
+    __syncthreads();
+    return fminf(fminf(misc[0], misc[1]), fminf(misc[2], misc[3]));
+}
+
+// Fold one tile group into the block's running (min, exp-sum, weighted-noise sums); called
+// after wsum[][] and misc[4..7] are written and a barrier has passed.
+//   misc : [8] LDS floats, wsum : [4][TAp] LDS, nrun : [TAp] LDS (thread n owns nrun[n])
+__device__ __forceinline__ void fold_tile(RunState& rs, float m_t, const float* misc,
+                                          const float* wsum, float* nrun, int TAp, int TA,
+                                          float inv_lambda, bool first)
+{
+    const float s_t = ((misc[4] + misc[5]) + misc[6]) + misc[7];
+    float alpha, gamma;
+    float Mn;
+    if (first) {
+        Mn = m_t; alpha = 0.0f; gamma = 1.0f;
+    } else {
+        Mn = fminf(rs.M, m_t);
+        alpha = expf(-inv_lambda * (rs.M - Mn));
+        gamma = expf(-inv_lambda * (m_t - Mn));
+    }
+    for (int n = threadIdx.x; n < TA; n += kRolloutThreads) {
+        const float tot = ((wsum[n] + wsum[TAp + n]) + wsum[2 * TAp + n]) + wsum[3 * TAp + n];
+        const float old = first ? 0.0f : nrun[n];
+        nrun[n] = alpha * old + gamma * tot;
+    }
+    rs.S = first ? s_t : alpha * rs.S + gamma * s_t;
+    rs.M = Mn;
+}
+
+__device__ __forceinline__ void stage_controls(const RolloutArgs& g, float4* ulds)
+{   // nominal controls into LDS, one float4 per Philox block, zero padded past T*A
+    const float* Uin = g.U + (g.solve_idx & 1ull) * g.TA;
+    for (int b = threadIdx.x; b < g.NBTp; b += kRolloutThreads) {
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = b * 4 + i;
+            u[i] = (n < g.TA) ? Uin[n] : 0.0f;
+        }
+        ulds[b] = make_float4(u[0], u[1], u[2], u[3]);
+    }
+}
+
+
+}  // namespace mppi

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -90,6 +91,8 @@ struct mppi_engine {
     float* h_act = nullptr;     // pinned + mapped
     float* h_act_dev = nullptr; // device alias of h_act
     float* d_local_partial = nullptr;  // TA+2 (sharded path)
+    float* d_slab = nullptr;           // combine row-split sums
+    unsigned int* d_tickets = nullptr; // combine arrival counters
     float* d_Einj = nullptr;    // injected noise, [K][T][A]
     bool injected = false, inj_dirty = false;
     float* d_scratch = nullptr; // export / trace / weights scratch
@@ -305,8 +308,14 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     ca.act_dev = e->d_act;
     ca.act_host = e->h_act_dev;
     ca.partial_out = partial_out;
+    ca.slab = e->d_slab;
+    ca.tickets = e->d_tickets;
     ca.solve_idx = e->solve_idx;
     ca.final_mode = final_mode ? 1 : 0;
+    {
+        const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
+        ca.row_splits = env ? atoi(env) : 0;
+    }
     HIPCHK(mppi::launch_combine(ca, st));
     return MPPI_OK;
 }
@@ -348,6 +357,12 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     HIPCHK(hipMalloc(&e->d_cost, (size_t)K * sizeof(float)));
     HIPCHK(hipMalloc(&e->d_act, 4 * sizeof(float)));
     HIPCHK(hipMalloc(&e->d_local_partial, (size_t)(e->TA + 2) * sizeof(float)));
+    HIPCHK(hipMalloc(&e->d_slab, (size_t)mppi::kMaxRowSplits * e->TA * sizeof(float)));
+    {
+        const size_t nt = (size_t)(e->TA + mppi::kCombineCols - 1) / mppi::kCombineCols;
+        HIPCHK(hipMalloc(&e->d_tickets, nt * sizeof(unsigned int)));
+        HIPCHK(hipMemset(e->d_tickets, 0, nt * sizeof(unsigned int)));
+    }
     HIPCHK(hipHostMalloc(&e->h_act, 4 * sizeof(float), hipHostMallocMapped));
     memset(e->h_act, 0, 4 * sizeof(float));
     HIPCHK(hipHostGetDevicePointer((void**)&e->h_act_dev, e->h_act, 0));
@@ -405,6 +420,8 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_pN);
     (void)hipFree(e->d_act);
     (void)hipFree(e->d_local_partial);
+    (void)hipFree(e->d_slab);
+    (void)hipFree(e->d_tickets);
     (void)hipFree(e->d_Einj);
     (void)hipFree(e->d_scratch);
     if (e->h_act) (void)hipHostFree(e->h_act);

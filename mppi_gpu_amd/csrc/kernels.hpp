@@ -76,14 +76,19 @@ struct CombineArgs {
     float* act_host;       // pinned, host-mapped; may be null
     // partial mode: out[0]=beta_g, out[1]=S_g, out[2..2+TA)=N_g
     float* partial_out;
+    float* slab;           // [kMaxRowSplits][TA] row-split sums (RS > 1)
+    unsigned int* tickets; // [ceil(TA/64)] arrival counters, zero between launches
     unsigned long long solve_idx;
     int final_mode;
+    int row_splits;        // 0 = auto (8 rows per wave)
 };
 
 constexpr int kRolloutThreads = 256;
 constexpr int kCombineThreads = 1024;
-constexpr int kCombineCols = 64;
+constexpr int kCombineCols = 32;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
+constexpr int kMaxRowSplits = 32;
+constexpr int kParamFloats = 32;   // LDS floats holding the problem constants in the fused rollout
 
 // Group geometry by action dimension and the instantiated register-resident chunk lengths
 // (template NG = groups per lane); pick returns the smallest instantiated NG >= ng, 0 if none.

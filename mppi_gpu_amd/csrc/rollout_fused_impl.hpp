@@ -1,0 +1,363 @@
+// rollout_fused_impl.hpp -- the fused rollout kernel template and its per-act_dim launcher.
+// Instantiated once per act_dim in rollout_fused_a{1,2,3,4}.hip so the four translation units
+// compile in parallel.
+#pragma once
+#include "device_common.hpp"
+
+namespace mppi {
+
+// ------------------------------------------------------------------------------------------
+// Fused rollout: 2^LOGC lanes per trajectory, NG groups per lane, noise resident in registers.
+//
+// Arithmetic: unlike the strict kernel this one lets products feed additions as FMAs
+// (explicit fmaf), as nvcc does by default for the reference's device code; the chunk
+// hand-over and the cost tree re-associate anyway, so its results are the same few-ulp
+// class either way (tests state the bound).
+// ------------------------------------------------------------------------------------------
+template <int A>
+struct LaneParams {     // wave-uniform problem constants, deliberately held in VGPRs: as kernel
+    float goal[2 * A];  // arguments they and the launch geometry exceed the 102-SGPR file and
+    float w[2 * A];     // every spilled scalar costs a v_readlane + s_nop in the hot loop
+    float sigma[A];
+    float dt, B0, dt2;
+};
+
+
+template <int A, int NG, bool SAMPLE, int LOGC>
+__device__ __forceinline__ void fused_body(const RolloutArgs& g)
+{
+    constexpr int SG = Dim<A>::SG;
+    constexpr int BPG = Dim<A>::BPG;
+    constexpr int NE = NG * BPG * 4;          // normals held per lane
+    constexpr int C = 1 << LOGC;
+
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBTp] U in block layout
+    float4* uclds = ulds + g.NBTp;                               // [NBTp] lambda*inv_s*U
+    float* plds = reinterpret_cast<float*>(uclds + g.NBTp);      // [kParamFloats]
+    const int nq = g.nq;                                         // blocks per lane = ng*BPG
+    const int TAp = C * nq * 4;
+    float* wsum = plds + kParamFloats;                           // [4][TAp]
+    float* nrun = wsum + 4 * TAp;                                // [TAp]
+    float* misc = nrun + TAp;                                    // [8]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & (C - 1);
+    const int ng = g.ng;
+
+    // ---- stage U, lambda*inv_s*U and the problem constants in LDS --------------------------
+    {
+        const float* Uin = g.U + (g.solve_idx & 1ull) * g.TA;
+        for (int b = threadIdx.x; b < g.NBTp; b += kRolloutThreads) {
+            float u[4], uc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = b * 4 + i;
+                u[i] = (n < g.TA) ? Uin[n] : 0.0f;
+                uc[i] = g.lambda * (u[i] * g.inv_s[(b * 4 + i) % A]);
+            }
+            ulds[b] = make_float4(u[0], u[1], u[2], u[3]);
+            uclds[b] = make_float4(uc[0], uc[1], uc[2], uc[3]);
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * A; ++i) {
+                plds[i] = g.goal[i];
+                plds[8 + i] = g.w[i];
+                plds[16 + i] = g.dev->x0[i];
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) plds[24 + i] = g.sigma[i];
+            plds[28] = g.dt;
+            plds[29] = g.B0;
+        }
+    }
+    __syncthreads();
+    LaneParams<A> P;
+    float x0p[A], x0v[A];
+#pragma unroll
+    for (int i = 0; i < 2 * A; ++i) { P.goal[i] = plds[i]; P.w[i] = plds[8 + i]; }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        P.sigma[i] = plds[24 + i];
+        x0p[i] = plds[16 + i];
+        x0v[i] = plds[16 + A + i];
+    }
+    P.dt = plds[28];
+    P.B0 = plds[29];
+    P.dt2 = P.dt * P.dt;
+
+    // chunk geometry of this lane (same for every tile group)
+    const int L = g.L;                                         // steps per full chunk
+    const int ns_own = (c < g.c_last) ? L : (c == g.c_last ? g.n_last : 0);
+    const int nbefore = min(c * L, g.T);
+    const unsigned long long blk0 = g.solve_idx * (unsigned long long)g.NBT
+                                    + (unsigned long long)(c * nq);
+    const float Lm1 = (float)(L - 1);
+
+    RunState rs{INFINITY, 0.0f};
+    bool first = true;
+
+    for (int tb = blockIdx.x; tb < g.n_tileblk; tb += gridDim.x) {
+        const long long gid = (long long)tb * kRolloutThreads + threadIdx.x;
+        const long long kloc = gid >> LOGC;
+        const bool valid = kloc < g.K;
+        const unsigned long long kglob = (unsigned long long)(g.k_offset + kloc);
+        const size_t tile = (size_t)(gid >> 6);
+        float* etile = g.Eint + ((tile * nq) * 64 + lane) * 4;    // + q*256 floats per block
+
+        // ---- pass 1: draw (or load) the chunk's noise into registers and store it; the
+        //      chunk's zero-state response is two weighted sums of a = u + e:
+        //      V = dt*S1,  P = B0*S1 + dt^2*((L-1)*S1 - S2),  S1 = sum a_j, S2 = sum j*a_j.
+        //      No masking: what a partial or empty chunk adds past the horizon is not used. ---
+        float e[NE];
+        float S1[A], S2[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+            for (int i = 0; i < BPG * 4; ++i) e[gi * BPG * 4 + i] = 0.f;
+            if (gi < ng) {
+                float u[BPG * 4];
+#pragma unroll
+                for (int j = 0; j < BPG; ++j) {
+                    const int q = gi * BPG + j;
+                    float* eq = &e[q * 4];
+                    if constexpr (SAMPLE) {
+                        const uint4 r = PhiloxAt::block(blk0 + (unsigned long long)q, kglob, g.seed);
+                        float z[4];
+                        box_muller_hw(r.x, r.y, z[0], z[1]);
+                        box_muller_hw(r.z, r.w, z[2], z[3]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
+                        *reinterpret_cast<float4*>(etile + (size_t)q * 256) =
+                            make_float4(eq[0], eq[1], eq[2], eq[3]);
+                    } else {
+                        const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
+                        eq[0] = t.x; eq[1] = t.y; eq[2] = t.z; eq[3] = t.w;
+                    }
+                    const float4 u4 = ulds[c * nq + q];
+                    u[j * 4 + 0] = u4.x; u[j * 4 + 1] = u4.y; u[j * 4 + 2] = u4.z; u[j * 4 + 3] = u4.w;
+                }
+#pragma unroll
+                for (int s = 0; s < SG; ++s) {
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        const float a = u[s * A + i] + e[gi * BPG * 4 + s * A + i];
+                        S1[i] += a;
+                        S2[i] = fmaf((float)(gi * SG + s), a, S2[i]);
+                    }
+                }
+            }
+        }
+        float Pz[A], Vz[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            Vz[i] = P.dt * S1[i];
+            Pz[i] = fmaf(P.dt2, fmaf(Lm1, S1[i], -S2[i]), P.B0 * S1[i]);
+            if (ns_own == 0) { Pz[i] = 0.f; Vz[i] = 0.f; }
+        }
+
+        // ---- affine scan over the C chunks: (n, P, V) o (n', P', V') =
+        //      (n + n', P + n'*dt*V + P', V + V') ------------------------------------------
+        {
+            int nacc = ns_own;
+#define MPPI_SCAN_LEVEL(D)                                                          \
+            if constexpr (C > (D)) {                                                \
+                const int nl = lane_up_i<(D), LOGC>(nacc);                          \
+                float Pl[A], Vl[A];                                                 \
+                _Pragma("unroll") for (int i = 0; i < A; ++i) {                     \
+                    Pl[i] = lane_up<(D), LOGC>(Pz[i]);                              \
+                    Vl[i] = lane_up<(D), LOGC>(Vz[i]);                              \
+                }                                                                   \
+                if (c >= (D)) {                                                     \
+                    const float tau = (float)nacc * P.dt;                           \
+                    _Pragma("unroll") for (int i = 0; i < A; ++i) {                 \
+                        Pz[i] = fmaf(tau, Vl[i], Pl[i]) + Pz[i];                    \
+                        Vz[i] = Vl[i] + Vz[i];                                      \
+                    }                                                               \
+                    nacc += nl;                                                     \
+                }                                                                   \
+            }
+            MPPI_SCAN_LEVEL(1)
+            MPPI_SCAN_LEVEL(2)
+            MPPI_SCAN_LEVEL(4)
+            MPPI_SCAN_LEVEL(8)
+            MPPI_SCAN_LEVEL(16)
+            MPPI_SCAN_LEVEL(32)
+#undef MPPI_SCAN_LEVEL
+        }
+        float p[A], v[A];
+        {
+            const float tau0 = (float)nbefore * P.dt;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                float Pex = 0.f, Vex = 0.f;
+                if constexpr (C > 1) {
+                    Pex = lane_up<1, LOGC>(Pz[i]);
+                    Vex = lane_up<1, LOGC>(Vz[i]);
+                    if (c == 0) { Pex = 0.f; Vex = 0.f; }
+                }
+                p[i] = fmaf(tau0, x0v[i], x0p[i]) + Pex;
+                v[i] = x0v[i] + Vex;
+            }
+        }
+
+        // ---- pass 2: dynamics + stage cost over the own chunk (src/point_mass_gpu.cu:97-107,
+        //      src/cost.cu:42-55).  No per-step masking: the chunk that holds step T-1 takes a
+        //      snapshot (cost so far, state) at the wave-uniform step n_last and uses that. ----
+        float cpart = 0.0f, cT = 0.0f;
+        float pT[A], vT[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { pT[i] = 0.f; vT[i] = 0.f; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi < ng) {
+                float u[BPG * 4], uc[BPG * 4];
+#pragma unroll
+                for (int j = 0; j < BPG; ++j) {
+                    const float4 u4 = ulds[c * nq + gi * BPG + j];
+                    const float4 c4 = uclds[c * nq + gi * BPG + j];
+                    u[j * 4 + 0] = u4.x; u[j * 4 + 1] = u4.y; u[j * 4 + 2] = u4.z; u[j * 4 + 3] = u4.w;
+                    uc[j * 4 + 0] = c4.x; uc[j * 4 + 1] = c4.y; uc[j * 4 + 2] = c4.z; uc[j * 4 + 3] = c4.w;
+                }
+#pragma unroll
+                for (int s = 0; s < SG; ++s) {
+                    const int sl = gi * SG + s;
+                    const float* es = &e[gi * BPG * 4 + s * A];
+                    float r = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        const float a = u[s * A + i] + es[i];
+                        const float pn = fmaf(P.B0, a, fmaf(P.dt, v[i], p[i]));
+                        v[i] = fmaf(P.dt, a, v[i]);
+                        p[i] = pn;
+                        r = fmaf(uc[s * A + i], es[i], r);
+                    }
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        const float d = p[i] - P.goal[i];
+                        r = fmaf(d * P.w[i], d, r);
+                    }
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        const float d = v[i] - P.goal[A + i];
+                        r = fmaf(d * P.w[A + i], d, r);
+                    }
+                    cpart += r;
+                    if (sl + 1 == g.n_last) {                  // wave-uniform
+                        cT = cpart;
+#pragma unroll
+                        for (int i = 0; i < A; ++i) { pT[i] = p[i]; vT[i] = v[i]; }
+                    }
+                }
+            }
+        }
+        {
+            float fc = 0.0f;    // Cost::final_cost (src/cost.cu:57-64) on the state after step T-1
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float d = pT[i] - P.goal[i];
+                fc = fmaf(d * P.w[i], d, fc);
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float d = vT[i] - P.goal[A + i];
+                fc = fmaf(d * P.w[A + i], d, fc);
+            }
+            cpart = (c < g.c_last) ? cpart : (c == g.c_last ? cT + fc : 0.0f);
+        }
+        const float cost = group_sum<LOGC>(cpart);
+        if (valid && c == 0) g.cost[kloc] = cost;
+
+        // ---- block tail: min, exp weights, weighted noise sums ----------------------------
+        const float m_t = tile_min(valid ? cost : INFINITY, misc, wave, lane);
+        const float wt = valid ? expf(-g.inv_lambda * (cost - m_t)) : 0.0f;
+        {
+            const float sw = wave_sum(c == 0 ? wt : 0.0f);
+            if (lane == 0) misc[4 + wave] = sw;
+        }
+        const float wtN = ((long long)kglob < g.k_cover) ? wt : 0.0f;
+        float* wrow = wsum + wave * TAp + (lane * nq) * 4;       // valid for lane < C
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi < ng) {
+#pragma unroll
+                for (int i = 0; i < BPG * 4; ++i) {
+                    const float val = strided_sum<LOGC>(wtN * e[gi * BPG * 4 + i]);
+                    if (lane < C) wrow[gi * BPG * 4 + i] = val;
+                }
+            }
+        }
+        __syncthreads();
+        fold_tile(rs, m_t, misc, wsum, nrun, TAp, g.TA, g.inv_lambda, first);
+        first = false;
+        __syncthreads();
+    }
+
+    // ---- publish the block partial ----------------------------------------------------------
+    float* Nout = g.part_N + (size_t)blockIdx.x * g.TA;
+    for (int n = threadIdx.x; n < g.TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
+    if (threadIdx.x == 0) {
+        g.part_m[blockIdx.x] = rs.M;
+        g.part_s[blockIdx.x] = rs.S;
+    }
+}
+
+template <int A, int NG, bool SAMPLE>
+__global__ void __launch_bounds__(kRolloutThreads)
+k_rollout_fused(const RolloutArgs g)
+{
+    switch (g.logC) {      // wave-uniform: one specialised body per lanes-per-trajectory
+        case 0: fused_body<A, NG, SAMPLE, 0>(g); break;
+        case 1: fused_body<A, NG, SAMPLE, 1>(g); break;
+        case 2: fused_body<A, NG, SAMPLE, 2>(g); break;
+        case 3: fused_body<A, NG, SAMPLE, 3>(g); break;
+        case 4: fused_body<A, NG, SAMPLE, 4>(g); break;
+        case 5: fused_body<A, NG, SAMPLE, 5>(g); break;
+        default: fused_body<A, NG, SAMPLE, 6>(g); break;
+    }
+}
+
+template <int A, int NG>
+hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream_t st)
+{
+    const size_t lds = rollout_lds_bytes(a.NBTp, a.C * a.nq * 4);
+    if (sample)
+        hipLaunchKernelGGL((k_rollout_fused<A, NG, true>), dim3(grid), dim3(kRolloutThreads), lds,
+                           st, a);
+    else
+        hipLaunchKernelGGL((k_rollout_fused<A, NG, false>), dim3(grid), dim3(kRolloutThreads),
+                           lds, st, a);
+    return hipGetLastError();
+}
+
+template <int A>
+hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
+                                 hipStream_t st)
+{
+    if constexpr (A == 3) {
+        switch (NGt) {
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, st);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, st);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, st);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, st);
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (NGt) {
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, st);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, st);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, st);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, st);
+            case 13: return launch_fused_t<A, 13>(sample, grid, a, st);
+            case 20: return launch_fused_t<A, 20>(sample, grid, a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+}
+
+
+}  // namespace mppi
