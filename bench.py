@@ -103,26 +103,16 @@ def main():
 
     if N == 1:
         m = PointMassModel(K, T, float(c["dt"]), 2 * A, A)
+        sharded = None
     else:
-        m = PointMassModel(K, T, float(c["dt"]), 2 * A, A, k_offset=rank * K)
+        from mppi_gpu_amd.sharded import ShardedPointMassModel
+        sharded = ShardedPointMassModel(N * K, T, float(c["dt"]), 2 * A, A)
+        m = sharded.engine          # this rank's shard: samples [rank*K, (rank+1)*K)
     m.set_tuning(chunks=args.chunks, strict=args.strict, max_blocks=args.max_blocks)
     m.set_seed(0)
     m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
     geo = m.geometry()
-
-    stream = torch.cuda.current_stream().cuda_stream if N > 1 else None
-    if N > 1:
-        L = m.partial_len()
-        partial = torch.zeros(L, device="cuda", dtype=torch.float32)
-        gathered = torch.zeros(N * L, device="cuda", dtype=torch.float32)
-
-        def step():
-            m.solve_local_async(partial.data_ptr(), stream)
-            dist.all_gather_into_tensor(gathered, partial)
-            m.solve_finish_async(gathered.data_ptr(), N, stream)
-    else:
-        def step():
-            m.solve_async()
+    step = m.solve_async if sharded is None else sharded.solve_async
 
     def fence():
         if dist is not None:

@@ -137,6 +137,25 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);
 /* Launch geometry actually in use: chunks, blocks per chunk (nq), grid, block, strict. */
 int mppi_get_geometry(mppi_engine* e, int out[5]);
 
+/* ---- serial CPU controller ------------------------------------------------------------ */
+
+/* The reference's `class ControllerBase` (include/controller_base.hpp:7-42,
+ * src/controller_base.cpp:4-98: ctor (k, tau, dt, sDim, aDim), next(x), setActions) made real:
+ * one thread, one sample after the other, same noise stream and same pipeline as the GPU
+ * engine.  BASELINE config 1 (point_mass1d K=100 T=50, no GPU).  A controller of its own, never
+ * a fallback of the GPU entry points above.  C++ users include controller_base.hpp instead. */
+typedef struct mppi_cpu_controller mppi_cpu_controller;
+mppi_cpu_controller* mppi_cpu_create(int k, int tau, float dt, int s_dim, int a_dim);
+void mppi_cpu_destroy(mppi_cpu_controller* c);
+int mppi_cpu_set_data(mppi_cpu_controller* c, const float* u, const float* goal, const float* w);
+int mppi_cpu_set_params(mppi_cpu_controller* c, float lambda, const float* sigma,
+                        const float* inv_s);
+int mppi_cpu_set_seed(mppi_cpu_controller* c, unsigned long long seed);
+int mppi_cpu_set_noise(mppi_cpu_controller* c, const float* noise);
+int mppi_cpu_next(mppi_cpu_controller* c, const float* x, float* act);
+int mppi_cpu_get(mppi_cpu_controller* c, float* u, float* noise, float* cost, float* beta,
+                 float* nabla, float* weight);
+
 int mppi_device_count(void);
 const char* mppi_last_error(void);
 const char* mppi_version(void);

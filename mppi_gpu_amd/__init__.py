@@ -13,7 +13,7 @@ import numpy as np
 from . import _capi
 from ._capi import MppiError, check  # noqa: F401
 
-__all__ = ["PointMassModel", "MppiError", "device_count", "version"]
+__all__ = ["PointMassModel", "ControllerBase", "MppiError", "device_count", "version"]
 
 
 def _fp(a):
@@ -197,3 +197,72 @@ class PointMassModel:
         n = C.c_int()
         check(self._lib.mppi_kernel_ms(self._h, int(which), C.byref(avg), C.byref(n)))
         return avg.value, n.value
+
+
+class ControllerBase:
+    """The serial CPU MPPI controller: reference `class ControllerBase`
+    (include/controller_base.hpp:7-42; ctor (k, tau, dt, sDim, aDim), next(x), setActions) made
+    real in C++ (mppi_gpu_amd/csrc/controller_base.cpp).  BASELINE config 1; needs no GPU and is
+    never used as a fallback by PointMassModel."""
+
+    def __init__(self, k, tau, dt, sDim, aDim):
+        self._lib = _capi.load()
+        self.K, self.T, self.S, self.A = int(k), int(tau), int(sDim), int(aDim)
+        self._h = self._lib.mppi_cpu_create(self.K, self.T, float(dt), self.S, self.A)
+        if not self._h:
+            raise ValueError("ControllerBase: invalid dimensions")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mppi_cpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setActions(self, actions):
+        u = _f32(actions, self.T * self.A, "actions")
+        null = C.cast(None, _capi.c_float_p)
+        check(self._lib.mppi_cpu_set_data(self._h, _fp(u), null, null))
+        return True
+
+    def setCost(self, goal, w):
+        g = _f32(goal, self.S, "goal")
+        ww = _f32(w, self.S, "w")
+        check(self._lib.mppi_cpu_set_data(self._h, C.cast(None, _capi.c_float_p), _fp(g), _fp(ww)))
+
+    def setParams(self, lam=1.0, sigma=None, inv_s=None):
+        null = C.cast(None, _capi.c_float_p)
+        s = _f32(sigma, self.A, "sigma") if sigma is not None else None
+        i = _f32(inv_s, self.A, "inv_s") if inv_s is not None else None
+        check(self._lib.mppi_cpu_set_params(self._h, float(lam), _fp(s) if s is not None else null,
+                                            _fp(i) if i is not None else null))
+
+    def setSeed(self, seed):
+        check(self._lib.mppi_cpu_set_seed(self._h, int(seed)))
+
+    def setNoise(self, E):
+        if E is None:
+            check(self._lib.mppi_cpu_set_noise(self._h, C.cast(None, _capi.c_float_p)))
+        else:
+            e = _f32(E, self.K * self.T * self.A, "E")
+            check(self._lib.mppi_cpu_set_noise(self._h, _fp(e)))
+
+    def next(self, x):
+        xx = _f32(x, self.S, "x")
+        act = np.empty(self.A, np.float32)
+        check(self._lib.mppi_cpu_next(self._h, _fp(xx), _fp(act)))
+        return act
+
+    def state(self):
+        u = np.empty((self.T, self.A), np.float32)
+        e = np.empty((self.K, self.T, self.A), np.float32)
+        cost = np.empty(self.K, np.float32)
+        w = np.empty(self.K, np.float32)
+        b = np.empty(1, np.float32)
+        n = np.empty(1, np.float32)
+        check(self._lib.mppi_cpu_get(self._h, _fp(u), _fp(e), _fp(cost), _fp(b), _fp(n), _fp(w)))
+        return dict(u=u, e=e, cost=cost, weight=w, beta=float(b[0]), nabla=float(n[0]))

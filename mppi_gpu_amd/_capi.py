@@ -43,6 +43,14 @@ SIGNATURES = {
     "mppi_set_profiling": (C.c_int, [engine_p, C.c_int]),
     "mppi_kernel_ms": (C.c_int, [engine_p, C.c_int, c_double_p, c_int_p]),
     "mppi_get_geometry": (C.c_int, [engine_p, c_int_p]),
+    "mppi_cpu_create": (C.c_void_p, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
+    "mppi_cpu_destroy": (None, [C.c_void_p]),
+    "mppi_cpu_set_data": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),
+    "mppi_cpu_set_params": (C.c_int, [C.c_void_p, C.c_float, c_float_p, c_float_p]),
+    "mppi_cpu_set_seed": (C.c_int, [C.c_void_p, C.c_ulonglong]),
+    "mppi_cpu_set_noise": (C.c_int, [C.c_void_p, c_float_p]),
+    "mppi_cpu_next": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "mppi_cpu_get": (C.c_int, [C.c_void_p] + [c_float_p] * 6),
     "mppi_device_count": (C.c_int, []),
     "mppi_last_error": (C.c_char_p, []),
     "mppi_version": (C.c_char_p, []),

@@ -1,0 +1,87 @@
+"""Sample-sharded MPPI over the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU rehearsal tests).
+
+The K samples of a solve are independent, so rank r owns the contiguous range
+[k_begin, k_end) of the global batch and draws its noise from the Philox subsequences of those
+GLOBAL indices: the noise, and therefore the controls, do not depend on the number of ranks.
+The only exchange per solve is one all-gather of T*A+2 floats per rank,
+    [beta_g, S_g, N_g[T*A]]   beta_g = min cost, S_g = sum exp(-(c-beta_g)/lambda),
+                              N_g    = sum exp(-(c-beta_g)/lambda) * E
+after which every rank combines the G partials in rank order (bitwise identical on all ranks):
+    beta = min beta_g, r_g = exp(-(beta_g-beta)/lambda), nabla = sum r_g S_g,
+    U += sum r_g N_g / nabla, then the shift.
+The reference has no multi-GPU path; this is new.
+"""
+from . import PointMassModel
+
+
+def shard_range(k_global, rank, world):
+    """Contiguous, balanced split of range(k_global): the first k_global % world ranks get one
+    sample more.  Returns (k_begin, k_end)."""
+    if not (0 <= rank < world) or k_global < world:
+        raise ValueError("need 0 <= rank < world <= k_global")
+    base, extra = divmod(k_global, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class ShardedPointMassModel:
+    """PointMassModel over all ranks of `group`.  Same call protocol as the reference class
+    (memcpy_set_data once, then get_act / set_x per control step); every rank must make the
+    same calls and gets the same action back.
+
+    engine_factory / tensor_factory exist so that the CPU rehearsal tests can run the identical
+    orchestration code (shard ranges, gather layout, call order) over gloo with a stand-in for
+    the two GPU entry points; production code never passes them."""
+
+    def __init__(self, nb_sim_global, steps, dt, state_dim, act_dim, group=None,
+                 engine_factory=None, tensor_factory=None):
+        import torch
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.K_global = int(nb_sim_global)
+        self.k_begin, self.k_end = shard_range(self.K_global, self.rank, self.world)
+        k_local = self.k_end - self.k_begin
+        make = engine_factory or (lambda k, off: PointMassModel(k, steps, dt, state_dim, act_dim,
+                                                                k_offset=off))
+        self.engine = make(k_local, self.k_begin)
+        self.L = self.engine.partial_len()
+        if tensor_factory is None:
+            def tensor_factory(n):
+                return torch.zeros(n, device="cuda", dtype=torch.float32)
+        self._partial = tensor_factory(self.L)
+        self._gathered = tensor_factory(self.L * self.world)
+        self._stream = None
+        if self._partial.is_cuda:
+            self._stream = torch.cuda.current_stream().cuda_stream
+
+    def memcpy_set_data(self, x, u, goal, w):
+        self.engine.memcpy_set_data(x, u, goal, w)
+
+    def set_x(self, x):
+        self.engine.set_x(x)
+
+    def solve_async(self):
+        """Enqueue one sharded solve: local rollout + reduction, all-gather, combine."""
+        self.engine.solve_local_async(self._partial.data_ptr(), self._stream)
+        self._dist.all_gather_into_tensor(self._gathered, self._partial, group=self._group)
+        self.engine.solve_finish_async(self._gathered.data_ptr(), self.world, self._stream)
+
+    def get_act(self):
+        self.solve_async()
+        return self.sync_act()
+
+    def sync_act(self):
+        if self._stream is not None:
+            import torch
+            torch.cuda.current_stream().synchronize()
+        return self.engine.sync_act()
+
+    def get_u(self):
+        return self.engine.get_u()
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,49 @@
+// host_loop.cpp -- a C++ host written against the REFERENCE's controller interface
+// (class PointMassModel; call protocol of reference src/main.cu:309-374: ctor ->
+// memcpy_set_data -> loop { get_u, get_act, plant step, set_x }), compiled with plain g++ and
+// linked against libmppi_gpu_amd.so.  Shows that the library is a link-level drop-in for that
+// path; the plant is a stand-in double integrator (MuJoCo is out of scope and its licence is
+// expired).  Prints one line per control step; the GPU test compares the numbers
+// with the same run driven through the C ABI from Python.
+#include "point_mass.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char** argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 2000;      // samples
+    const int steps = argc > 2 ? atoi(argv[2]) : 50;    // horizon
+    const int iters = argc > 3 ? atoi(argv[3]) : 5;
+    const int act_dim = 2, state_dim = 4;
+    const float dt = 0.1f;
+
+    std::vector<float> x(state_dim, 0.0f), u(steps * act_dim, 0.0f), next_act(act_dim);
+    float goal[4] = {1, 0, 0, 0};            // reference config/point_mass2d.yaml
+    float w[4] = {1, 1, 50, 50};
+
+    PointMassModel* model = new PointMassModel(n, steps, dt, state_dim, act_dim, false);
+    model->set_seed(11);
+    model->memcpy_set_data(x.data(), u.data(), goal, w);
+
+    std::vector<float> u_prev(steps * act_dim);
+    for (int it = 0; it < iters; ++it) {
+        model->get_u(u_prev.data());
+        model->get_act(next_act.data());
+        printf("ACT %d %.9g %.9g\n", it, next_act[0], next_act[1]);
+        // stand-in plant: the same double integrator, one step
+        for (int a = 0; a < act_dim; ++a) {
+            const float p = x[a] + dt * x[a + 2] + 0.5f * dt * dt * next_act[a];
+            const float v = x[a + 2] + dt * next_act[a];
+            x[a] = p;
+            x[a + 2] = v;
+        }
+        model->set_x(x.data());
+    }
+    std::vector<float> xr(state_dim);
+    model->get_x(xr.data());
+    printf("X %.9g %.9g %.9g %.9g\n", xr[0], xr[1], xr[2], xr[3]);
+    delete model;
+    return 0;
+}

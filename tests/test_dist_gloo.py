@@ -1,0 +1,123 @@
+"""World-size-2 rehearsal of the sharded path on CPU (gloo): the REAL orchestration code
+(mppi_gpu_amd/sharded.py: shard ranges, partial layout, all-gather, call order) runs in two
+processes; the two GPU entry points are replaced by a test double that computes the rank-local
+partial and the final combine with the CPU oracle / numpy.  The result must equal the oracle's
+single-process solve of the whole batch.  (The GPU kernels behind the same two entry points are
+checked against a single engine in tests/test_gpu_parity.py::test_sharded_engines_equal_single_engine.)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as ol  # noqa: E402
+
+
+class _OracleShardEngine:
+    """Test double for the two sharded entry points of the C ABI, on numpy + the oracle."""
+
+    def __init__(self, k_local, k_offset, case, seed):
+        self.c, self.seed = case, seed
+        self.K, self.off = k_local, k_offset
+        self.T, self.A = case["U"].shape
+        self.U = case["U"].copy()
+        self.x0 = case["x0"].copy()
+        self.solve_idx = 0
+        self.act = None
+
+    def partial_len(self):
+        return self.T * self.A + 2
+
+    def memcpy_set_data(self, x, u, goal, w):
+        self.x0, self.U = np.asarray(x, np.float32), np.asarray(u, np.float32).reshape(self.T, self.A)
+
+    def solve_local_async(self, ptr, stream):
+        E = ol.noise(self.seed, self.solve_idx, self.off, self.K, self.T, self.A, [0.025] * self.A)
+        cost = ol.rollout(self.x0, self.U, E, self.c["goal"], self.c["w"], self.c["dt"])
+        beta = cost.min()
+        ex = np.exp(-(cost - beta).astype(np.float64))
+        out = np.concatenate([[beta, ex.sum()], (ex[:, None] * E.reshape(self.K, -1)).sum(0)])
+        self._out_tensor.copy_(torch.from_numpy(out.astype(np.float32)))
+
+    def solve_finish_async(self, ptr, n_parts, stream):
+        g = self._gathered_tensor.numpy().reshape(n_parts, -1).astype(np.float64)
+        beta = g[:, 0].min()
+        r = np.exp(-(g[:, 0] - beta))
+        nabla = (r * g[:, 1]).sum()
+        dU = (r[:, None] * g[:, 2:]).sum(0) / nabla
+        full = (self.U.reshape(-1).astype(np.float64) + dU).astype(np.float32).reshape(self.T, self.A)
+        self.act = full[0].copy()
+        self.U = np.concatenate([full[1:], full[-1:]])
+        self.solve_idx += 1
+
+    def sync_act(self):
+        return self.act
+
+    def get_u(self):
+        return self.U
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, K, A, T, seed, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mppi_gpu_amd.sharded import ShardedPointMassModel, shard_range
+    case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
+    engines = {}
+
+    def factory(k, off):
+        engines["e"] = _OracleShardEngine(k, off, case, seed)
+        return engines["e"]
+
+    m = ShardedPointMassModel(K, T, float(case["dt"]), 2 * A, A, engine_factory=factory,
+                              tensor_factory=lambda n: torch.zeros(n, dtype=torch.float32))
+    engines["e"]._out_tensor = m._partial
+    engines["e"]._gathered_tensor = m._gathered
+    assert (m.k_begin, m.k_end) == shard_range(K, rank, world)
+    m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
+    acts = [m.get_act().copy() for _ in range(3)]
+    ret[rank] = (np.stack(acts), m.get_u().copy(), m.k_begin, m.k_end)
+    dist.destroy_process_group()
+
+
+def test_shard_range_is_a_partition():
+    from mppi_gpu_amd.sharded import shard_range
+    for K, W in ((10, 3), (1000000, 8), (8, 8), (100001, 4)):
+        spans = [shard_range(K, r, W) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == K
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(3, 0, 4)
+
+
+def test_two_rank_gloo_sharded_solve_equals_single_process_oracle():
+    K, A, T, seed, world = 301, 3, 40, 17, 2          # uneven split: 151 + 150
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, K, A, T, seed, ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    acts0, U0, b0, e0 = ret[0]
+    acts1, U1, b1, e1 = ret[1]
+    assert (b0, e0, b1, e1) == (0, 151, 151, 301)
+    assert np.array_equal(acts0, acts1) and np.array_equal(U0, U1), "ranks must agree bitwise"
+    # single-process oracle on the whole batch, same global noise stream
+    case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
+    U, x0 = case["U"].copy(), case["x0"]
+    for it in range(3):
+        E = ol.noise(seed, it, 0, K, T, A, [0.025] * A)
+        ref = ol.solve(x0, U, E, case["goal"], case["w"], case["dt"])
+        scale = max(float(np.abs(ref["U"]).max()), 0.025)
+        assert np.abs(acts0[it] - ref["next_act"]).max() <= 1e-5 * scale, it
+        U = ref["U"]
+    assert np.abs(U0 - U).max() <= 1e-5 * max(float(np.abs(U).max()), 0.025)
