@@ -105,7 +105,7 @@ struct mppi_engine {
     int prof = 0;                   // 0 = off, n = record every n-th solve
     bool prof_now = false;
     unsigned long long prof_count = 0;
-    std::vector<hipEvent_t> ev;     // 3 per solve: before rollout, after rollout, after combine
+    std::vector<hipEvent_t> ev;     // 4 per profiled solve: rollout start/stop, combine start/stop
     size_t ev_used = 0;
 };
 
@@ -250,16 +250,21 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     for (int i = 0; i < 4; ++i) { a.sigma[i] = e->sigma[i]; a.inv_s[i] = e->inv_s[i]; }
 }
 
-int prof_event(mppi_engine_t* e, hipStream_t st)
+// a start/stop event pair for the next launch, or an empty timing when this solve is not sampled
+int prof_pair(mppi_engine_t* e, mppi::LaunchTiming& tm)
 {
+    tm = mppi::LaunchTiming();
     if (!e->prof_now) return MPPI_OK;
-    if (e->ev_used == e->ev.size()) {
-        if (e->ev.size() >= 3 * 8192) return MPPI_OK;   // stop recording, keep running
-        hipEvent_t ne;
-        HIPCHK(hipEventCreate(&ne));
-        e->ev.push_back(ne);
+    if (e->ev_used + 2 > e->ev.size()) {
+        if (e->ev.size() >= 4 * 8192) return MPPI_OK;   // stop recording, keep running
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t ne;
+            HIPCHK(hipEventCreate(&ne));
+            e->ev.push_back(ne);
+        }
     }
-    HIPCHK(hipEventRecord(e->ev[e->ev_used++], st));
+    tm.start = e->ev[e->ev_used++];
+    tm.stop = e->ev[e->ev_used++];
     return MPPI_OK;
 }
 
@@ -277,12 +282,12 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
     mppi::RolloutArgs ra;
     fill_rollout_args(e, ra);
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
-    if ((rc = prof_event(e, st))) return rc;
+    mppi::LaunchTiming tm;
+    if ((rc = prof_pair(e, tm))) return rc;
     if (e->strict)
-        HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st));
+        HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st, tm));
     else
-        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, !e->injected, e->grid, ra, st));
-    if ((rc = prof_event(e, st))) return rc;
+        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, !e->injected, e->grid, ra, st, tm));
     e->last_C = e->C;
     e->last_nq = e->nq;
     e->last_idx = e->solve_idx;
@@ -316,7 +321,12 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
         const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
         ca.row_splits = env ? atoi(env) : 0;
     }
-    HIPCHK(mppi::launch_combine(ca, st));
+    mppi::LaunchTiming tm;
+    {
+        int rc = prof_pair(e, tm);
+        if (rc) return rc;
+    }
+    HIPCHK(mppi::launch_combine(ca, st, tm));
     return MPPI_OK;
 }
 
@@ -471,7 +481,6 @@ int mppi_solve_async(mppi_engine* e, void* stream)
     if (rc) return rc;
     rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, true, nullptr);
     if (rc) return rc;
-    if ((rc = prof_event(e, st))) return rc;
     e->solve_idx += 1;
     e->have_solve = true;
     return MPPI_OK;
@@ -624,8 +633,7 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     int rc = enqueue_rollout(e, st);
     if (rc) return rc;
     rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, false, d_partial);
-    if (rc) return rc;
-    return prof_event(e, st);
+    return rc;
 }
 
 int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream)
@@ -633,6 +641,7 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
     if (!e || !d_gathered) return fail(MPPI_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const long long stride = e->TA + 2;
+    e->prof_now = false;   // kernel_ms() reports the rollout and the rank-local combine only
     int rc = enqueue_combine(e, st, d_gathered, d_gathered + 1, d_gathered + 2, stride, stride,
                              stride, n_parts, true, nullptr);
     if (rc) return rc;
@@ -659,9 +668,9 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out)
     HIPCHK(hipDeviceSynchronize());
     double tot = 0.0;
     int n = 0;
-    for (size_t i = 0; i + 3 <= e->ev_used; i += 3) {
+    for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[i + which], e->ev[i + which + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[i + 2 * which], e->ev[i + 2 * which + 1]));
         tot += ms;
         ++n;
     }

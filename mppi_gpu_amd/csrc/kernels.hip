@@ -409,50 +409,51 @@ size_t rollout_lds_bytes(int NBTp, int TAp)
 }
 
 template <int A>
-hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a, hipStream_t st);
-extern template hipError_t launch_fused_a<1>(int, bool, int, const RolloutArgs&, hipStream_t);
-extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, hipStream_t);
-extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, hipStream_t);
-extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, hipStream_t);
+hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a, hipStream_t st,
+                          LaunchTiming tm);
+extern template hipError_t launch_fused_a<1>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
 
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
-                                hipStream_t st)
+                                hipStream_t st, LaunchTiming tm)
 {
     switch (A) {
-        case 1: return launch_fused_a<1>(NGt, sample, grid, a, st);
-        case 2: return launch_fused_a<2>(NGt, sample, grid, a, st);
-        case 3: return launch_fused_a<3>(NGt, sample, grid, a, st);
-        case 4: return launch_fused_a<4>(NGt, sample, grid, a, st);
+        case 1: return launch_fused_a<1>(NGt, sample, grid, a, st, tm);
+        case 2: return launch_fused_a<2>(NGt, sample, grid, a, st, tm);
+        case 3: return launch_fused_a<3>(NGt, sample, grid, a, st, tm);
+        case 4: return launch_fused_a<4>(NGt, sample, grid, a, st, tm);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int A>
-static hipError_t launch_stream_a(bool sample, int grid, const RolloutArgs& a, hipStream_t st)
+static hipError_t launch_stream_a(bool sample, int grid, const RolloutArgs& a, hipStream_t st,
+                                  LaunchTiming tm)
 {
     const size_t lds = rollout_lds_bytes(a.NBTp, a.nq * 4);
     if (sample)
-        hipLaunchKernelGGL((k_rollout_stream<A, true>), dim3(grid), dim3(kRolloutThreads), lds, st,
-                           a);
+        MPPI_LAUNCH((k_rollout_stream<A, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm, a);
     else
-        hipLaunchKernelGGL((k_rollout_stream<A, false>), dim3(grid), dim3(kRolloutThreads), lds,
-                           st, a);
+        MPPI_LAUNCH((k_rollout_stream<A, false>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
+                    a);
     return hipGetLastError();
 }
 
 hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
-                                 hipStream_t st)
+                                 hipStream_t st, LaunchTiming tm)
 {
     switch (A) {
-        case 1: return launch_stream_a<1>(sample, grid, a, st);
-        case 2: return launch_stream_a<2>(sample, grid, a, st);
-        case 3: return launch_stream_a<3>(sample, grid, a, st);
-        case 4: return launch_stream_a<4>(sample, grid, a, st);
+        case 1: return launch_stream_a<1>(sample, grid, a, st, tm);
+        case 2: return launch_stream_a<2>(sample, grid, a, st, tm);
+        case 3: return launch_stream_a<3>(sample, grid, a, st, tm);
+        case 4: return launch_stream_a<4>(sample, grid, a, st, tm);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st)
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm)
 {
     const int cols = (a.TA + kCombineCols - 1) / kCombineCols;
     // Row splits meet through an agent-scope ticket (~3 us of fences), so a single split with
@@ -462,11 +463,11 @@ hipError_t launch_combine(const CombineArgs& a, hipStream_t st)
     if (rs > kMaxRowSplits) rs = kMaxRowSplits;
     const int rows_per_wave = ((a.n_parts + rs - 1) / rs + 31) / 32;   // per row group
     if (rows_per_wave <= 8)
-        hipLaunchKernelGGL(k_combine<8>, dim3(cols, rs), dim3(kCombineThreads), 0, st, a);
+        MPPI_LAUNCH(k_combine<8>, dim3(cols, rs), dim3(kCombineThreads), 0, st, tm, a);
     else if (rows_per_wave <= 20)
-        hipLaunchKernelGGL(k_combine<20>, dim3(cols, rs), dim3(kCombineThreads), 0, st, a);
+        MPPI_LAUNCH(k_combine<20>, dim3(cols, rs), dim3(kCombineThreads), 0, st, tm, a);
     else
-        hipLaunchKernelGGL(k_combine<40>, dim3(cols, rs), dim3(kCombineThreads), 0, st, a);
+        MPPI_LAUNCH(k_combine<40>, dim3(cols, rs), dim3(kCombineThreads), 0, st, tm, a);
     return hipGetLastError();
 }
 

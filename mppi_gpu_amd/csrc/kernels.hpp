@@ -14,6 +14,7 @@
 //   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 
 namespace mppi {
@@ -98,11 +99,19 @@ int rollout_max_groups(int A);
 int rollout_pick_ng_template(int A, int ng);
 size_t rollout_lds_bytes(int NBTp, int TAp);
 
+// Optional dispatch timing: when both events are non-null the launch goes through
+// hipExtLaunchKernelGGL, which stamps the events with the dispatch packet's own start / end
+// times (the same timestamps rocprofv3 --kernel-trace reports), not with stream-order markers.
+struct LaunchTiming {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
+
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
-                                hipStream_t st);
+                                hipStream_t st, LaunchTiming tm = LaunchTiming());
 hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
-                                 hipStream_t st);
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st);
+                                 hipStream_t st, LaunchTiming tm = LaunchTiming());
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming());
 
 // debug / data-movement kernels (off the timed path)
 hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T, int C,
@@ -114,5 +123,15 @@ hipError_t launch_trace_states(int A, const float* Eint, const float* U_rollout,
                                hipStream_t st);
 hipError_t launch_weights(const float* cost, const DevState* dev, float lambda, float* wts,
                           int K, hipStream_t st);
+
+// launch with or without dispatch timing
+#define MPPI_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                       \
+    do {                                                                                         \
+        if ((tm).start && (tm).stop)                                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (tm).start, (tm).stop, 0,        \
+                                  __VA_ARGS__);                                                  \
+        else                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                       \
+    } while (0)
 
 }  // namespace mppi

@@ -1,5 +1,5 @@
 // explicit instantiation of the fused rollout launcher for act_dim = 2
 #include "rollout_fused_impl.hpp"
 namespace mppi {
-template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, hipStream_t);
+template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
 }

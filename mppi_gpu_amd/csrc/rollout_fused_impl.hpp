@@ -322,38 +322,39 @@ k_rollout_fused(const RolloutArgs g)
 }
 
 template <int A, int NG>
-hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream_t st)
+hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream_t st,
+                          LaunchTiming tm)
 {
     const size_t lds = rollout_lds_bytes(a.NBTp, a.C * a.nq * 4);
     if (sample)
-        hipLaunchKernelGGL((k_rollout_fused<A, NG, true>), dim3(grid), dim3(kRolloutThreads), lds,
-                           st, a);
+        MPPI_LAUNCH((k_rollout_fused<A, NG, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
+                    a);
     else
-        hipLaunchKernelGGL((k_rollout_fused<A, NG, false>), dim3(grid), dim3(kRolloutThreads),
-                           lds, st, a);
+        MPPI_LAUNCH((k_rollout_fused<A, NG, false>), dim3(grid), dim3(kRolloutThreads), lds, st,
+                    tm, a);
     return hipGetLastError();
 }
 
 template <int A>
 hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
-                                 hipStream_t st)
+                          hipStream_t st, LaunchTiming tm)
 {
     if constexpr (A == 3) {
         switch (NGt) {
-            case 1: return launch_fused_t<A, 1>(sample, grid, a, st);
-            case 2: return launch_fused_t<A, 2>(sample, grid, a, st);
-            case 4: return launch_fused_t<A, 4>(sample, grid, a, st);
-            case 7: return launch_fused_t<A, 7>(sample, grid, a, st);
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, st, tm);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, st, tm);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, st, tm);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, st, tm);
             default: return hipErrorInvalidValue;
         }
     } else {
         switch (NGt) {
-            case 1: return launch_fused_t<A, 1>(sample, grid, a, st);
-            case 2: return launch_fused_t<A, 2>(sample, grid, a, st);
-            case 4: return launch_fused_t<A, 4>(sample, grid, a, st);
-            case 7: return launch_fused_t<A, 7>(sample, grid, a, st);
-            case 13: return launch_fused_t<A, 13>(sample, grid, a, st);
-            case 20: return launch_fused_t<A, 20>(sample, grid, a, st);
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, st, tm);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, st, tm);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, st, tm);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, st, tm);
+            case 13: return launch_fused_t<A, 13>(sample, grid, a, st, tm);
+            case 20: return launch_fused_t<A, 20>(sample, grid, a, st, tm);
             default: return hipErrorInvalidValue;
         }
     }
