@@ -144,9 +144,19 @@ def main():
         c_ms, _ = m.kernel_ms(1)
         ab = algorithmic_bytes_rollout(K, T, A)
         ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # PMC traffic cannot be collected from inside the timed process: it comes from the
+        # committed rocprofv3 --pmc summary of this workload/geometry (tools_traffic.sh), if any
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+            ent = tj["entries"].get(f"{args.workload}:chunks={geo['chunks']}")
+            if ent and not geo["strict"]:
+                traffic = ent["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "hbm", "kernel": "k_rollout_fused" if not geo["strict"] else "k_rollout_stream",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
                 "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
 

@@ -132,8 +132,9 @@ __device__ __forceinline__ void fused_body(const RolloutArgs& g)
                         box_muller_hw(r.z, r.w, z[2], z[3]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
-                        *reinterpret_cast<float4*>(etile + (size_t)q * 256) =
-                            make_float4(eq[0], eq[1], eq[2], eq[3]);
+                        if (c * nq + q < g.NBT)      // blocks past the horizon are not stored
+                            *reinterpret_cast<float4*>(etile + (size_t)q * 256) =
+                                make_float4(eq[0], eq[1], eq[2], eq[3]);
                     } else {
                         const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
                         eq[0] = t.x; eq[1] = t.y; eq[2] = t.z; eq[3] = t.w;
