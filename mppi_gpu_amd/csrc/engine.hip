@@ -154,6 +154,7 @@ int ensure_geometry(mppi_engine_t* e)
             while (C < 64 && (NGT + C - 1) / C > ng_pref) C <<= 1;
             while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NGT + 2 * C - 1) / (2 * C) >= 4)
                 C <<= 1;
+        }
         ng = (NGT + C - 1) / C;
         NGt = mppi::rollout_pick_ng_template(e->A, ng);
         if (!NGt) return fail(MPPI_EINVAL, "no kernel for %d groups per lane", ng);
