@@ -32,6 +32,7 @@ WORKLOADS = {
     "c3": (3, 100_000, 200, "point_mass3d K=1e5 T=200 (BASELINE configs[2])"),
     "c4": (3, 125_000, 200, "point_mass3d K=1e6/8 per GPU T=200 (BASELINE configs[3] shard)"),
     "c1": (1, 100, 50, "point_mass1d K=100 T=50 (BASELINE configs[0] shape, on the GPU)"),
+    "floor": (2, 10_000, 8, "launch-floor probe: 2-D K=1e4 T=8 (not a BASELINE config)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 

@@ -115,15 +115,17 @@ __device__ __forceinline__ float wave_min(float x)
     return x;
 }
 
-// sum over the lanes {l : l % 2^LOGC == lane % 2^LOGC} of the wave; rotation based, so the
-// association differs per lane -- callers read fixed lanes only
+// sum over the lanes {l : l % 2^LOGC == lane % 2^LOGC} of the wave.  Rotations are applied in
+// DECREASING distance (8, 4, 2, 1): before the rotation by d the data is 2d-periodic within the
+// 16-lane row, so lane i and lane i^d add the same two operands (in swapped order) and every
+// lane of a group ends with the same bits; the row and half swaps are symmetric by construction.
 template <int LOGC>
-__device__ __forceinline__ float strided_sum(float x)
+__device__ __forceinline__ float symmetric_strided_sum(float x)
 {
-    if constexpr (LOGC <= 0) x += dpp<MPPI_ROW_ROR(1)>(x);
-    if constexpr (LOGC <= 1) x += dpp<MPPI_ROW_ROR(2)>(x);
-    if constexpr (LOGC <= 2) x += dpp<MPPI_ROW_ROR(4)>(x);
     if constexpr (LOGC <= 3) x += dpp<MPPI_ROW_ROR(8)>(x);
+    if constexpr (LOGC <= 2) x += dpp<MPPI_ROW_ROR(4)>(x);
+    if constexpr (LOGC <= 1) x += dpp<MPPI_ROW_ROR(2)>(x);
+    if constexpr (LOGC <= 0) x += dpp<MPPI_ROW_ROR(1)>(x);
     if constexpr (LOGC <= 4) { float a, b; swap16(x, a, b); x = a + b; }
     if constexpr (LOGC <= 5) { float a, b; swap32(x, a, b); x = a + b; }
     return x;
@@ -257,9 +259,10 @@ __device__ __forceinline__ void fold_tile(RunState& rs, float m_t, const float* 
     rs.M = Mn;
 }
 
-__device__ __forceinline__ void stage_controls(const RolloutArgs& g, float4* ulds)
+__device__ __forceinline__ void stage_controls(const RolloutArgs& g, unsigned long long solve_idx,
+                                               float4* ulds)
 {   // nominal controls into LDS, one float4 per Philox block, zero padded past T*A
-    const float* Uin = g.U + (g.solve_idx & 1ull) * g.TA;
+    const float* Uin = g.U + (solve_idx & 1ull) * g.TA;
     for (int b = threadIdx.x; b < g.NBTp; b += kRolloutThreads) {
         float u[4];
 #pragma unroll

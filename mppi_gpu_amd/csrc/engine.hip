@@ -91,6 +91,9 @@ struct mppi_engine {
     float* h_act = nullptr;     // pinned + mapped
     float* h_act_dev = nullptr; // device alias of h_act
     float* d_local_partial = nullptr;  // TA+2 (sharded path)
+    mppi::RolloutArgs* d_args = nullptr;   // launch descriptor in device memory
+    mppi::RolloutArgs h_args_last;         // what d_args currently holds
+    bool args_valid = false;
     float* d_slab = nullptr;           // combine row-split sums
     unsigned int* d_tickets = nullptr; // combine arrival counters
     float* d_Einj = nullptr;    // injected noise, [K][T][A]
@@ -252,6 +255,7 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.inv_lambda = 1 / e->lambda;
     for (int i = 0; i < 8; ++i) { a.goal[i] = e->goal[i]; a.w[i] = e->w[i]; }
     for (int i = 0; i < 4; ++i) { a.sigma[i] = e->sigma[i]; a.inv_s[i] = e->inv_s[i]; }
+    for (int i = 0; i < 8; ++i) a.x0[i] = e->x0[i];
 }
 
 // a start/stop event pair for the next launch, or an empty timing when this solve is not sampled
@@ -284,7 +288,20 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
         e->inj_dirty = false;
     }
     mppi::RolloutArgs ra;
+    memset(&ra, 0, sizeof ra);
     fill_rollout_args(e, ra);
+    ra.dev_copy = e->d_args;
+    {   // refresh the device copy only when something other than the solve index changed
+        mppi::RolloutArgs cmp = ra;
+        cmp.solve_idx = 0;
+        for (int i = 0; i < 8; ++i) cmp.x0[i] = 0.f;   // x0 travels by value
+        if (!e->args_valid || memcmp(&cmp, &e->h_args_last, sizeof cmp) != 0) {
+            HIPCHK(hipMemcpyAsync(e->d_args, &cmp, sizeof cmp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            e->h_args_last = cmp;
+            e->args_valid = true;
+        }
+    }
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
     mppi::LaunchTiming tm;
     if ((rc = prof_pair(e, tm))) return rc;
@@ -371,6 +388,7 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     HIPCHK(hipMalloc(&e->d_cost, (size_t)K * sizeof(float)));
     HIPCHK(hipMalloc(&e->d_act, 4 * sizeof(float)));
     HIPCHK(hipMalloc(&e->d_local_partial, (size_t)(e->TA + 2) * sizeof(float)));
+    HIPCHK(hipMalloc(&e->d_args, sizeof(mppi::RolloutArgs)));
     HIPCHK(hipMalloc(&e->d_slab, (size_t)mppi::kMaxRowSplits * e->TA * sizeof(float)));
     {
         const size_t nt = (size_t)(e->TA + mppi::kCombineCols - 1) / mppi::kCombineCols;
@@ -434,6 +452,7 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_pN);
     (void)hipFree(e->d_act);
     (void)hipFree(e->d_local_partial);
+    (void)hipFree(e->d_args);
     (void)hipFree(e->d_slab);
     (void)hipFree(e->d_tickets);
     (void)hipFree(e->d_Einj);

@@ -34,8 +34,9 @@ namespace mppi {
 // ------------------------------------------------------------------------------------------
 template <int A, bool SAMPLE>
 __global__ void __launch_bounds__(kRolloutThreads)
-k_rollout_stream(const RolloutArgs g)
+k_rollout_stream(const RolloutArgs* __restrict__ gp, const unsigned long long solve_idx)
 {
+    const RolloutArgs& g = *gp;
     constexpr int SG = Dim<A>::SG;
     constexpr int BPG = Dim<A>::BPG;
 
@@ -49,9 +50,9 @@ k_rollout_stream(const RolloutArgs g)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    stage_controls(g, ulds);
+    stage_controls(g, solve_idx, ulds);
     __syncthreads();
-    const unsigned long long blk0 = g.solve_idx * (unsigned long long)g.NBT;
+    const unsigned long long blk0 = solve_idx * (unsigned long long)g.NBT;
     const int n_groups = nq / BPG;
 
     RunState rs{INFINITY, 0.0f};
@@ -404,8 +405,8 @@ int rollout_pick_ng_template(int A, int ng)
 }
 
 size_t rollout_lds_bytes(int NBTp, int TAp)
-{   // u and lambda*inv_s*u blocks, constants, 4 per-wave rows + the running row, scratch
-    return (size_t)NBTp * 32 + (size_t)(kParamFloats + 5 * TAp + 8) * sizeof(float);
+{   // u and lambda*inv_s*u blocks, 4 per-wave rows + the running row, scratch
+    return (size_t)NBTp * 32 + (size_t)(5 * TAp + 8) * sizeof(float);
 }
 
 template <int A>
@@ -434,10 +435,11 @@ static hipError_t launch_stream_a(bool sample, int grid, const RolloutArgs& a, h
 {
     const size_t lds = rollout_lds_bytes(a.NBTp, a.nq * 4);
     if (sample)
-        MPPI_LAUNCH((k_rollout_stream<A, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm, a);
+        MPPI_LAUNCH((k_rollout_stream<A, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
+                    a.dev_copy, a.solve_idx);
     else
         MPPI_LAUNCH((k_rollout_stream<A, false>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
-                    a);
+                    a.dev_copy, a.solve_idx);
     return hipGetLastError();
 }
 

@@ -25,8 +25,10 @@ struct DevState {
     float nabla;
 };
 
-// Everything a rollout launch needs; passed by value (fits the kernarg segment).
+// Everything a rollout launch needs.  The kernels read it from device memory (dev_copy) and get
+// only the solve index by value.
 struct RolloutArgs {
+    const RolloutArgs* dev_copy;   // this descriptor in device memory (what the kernels read)
     const DevState* dev;
     const float* U;        // base of the 2 x TA double buffer
     float* Eint;           // tile-layout noise (written when sampling, read when injected)
@@ -59,7 +61,38 @@ struct RolloutArgs {
     float w[8];
     float sigma[4];
     float inv_s[4];
+    float x0[8];           // host copy of the current state (travels by value in RolloutHot)
 };
+
+// What the first instructions of the fused rollout need, passed BY VALUE as kernel arguments
+// (no dependent load in front of the Philox work); everything else is read through `rest`.
+struct RolloutHot {
+    const RolloutArgs* rest;   // the full descriptor in device memory
+    const float* U_in;         // nominal controls of this solve (already offset by parity)
+    float* Eint;
+    unsigned long long seed;
+    unsigned long long solve_idx;
+    long long k_offset;
+    int K, T, TA, NBT, NBTp;
+    int logC, ng, nq, L, c_last, n_last, n_tileblk;
+    float x0[8];
+};
+
+inline RolloutHot make_hot(const RolloutArgs& a)
+{
+    RolloutHot h;
+    h.rest = a.dev_copy;
+    h.U_in = a.U + (a.solve_idx & 1ull) * a.TA;
+    h.Eint = a.Eint;
+    h.seed = a.seed;
+    h.solve_idx = a.solve_idx;
+    h.k_offset = a.k_offset;
+    h.K = a.K; h.T = a.T; h.TA = a.TA; h.NBT = a.NBT; h.NBTp = a.NBTp;
+    h.logC = a.logC; h.ng = a.ng; h.nq = a.nq; h.L = a.L;
+    h.c_last = a.c_last; h.n_last = a.n_last; h.n_tileblk = a.n_tileblk;
+    for (int i = 0; i < 8; ++i) h.x0[i] = a.x0[i];
+    return h;
+}
 
 struct CombineArgs {
     DevState* dev;

@@ -13,133 +13,150 @@ namespace mppi {
 // (explicit fmaf), as nvcc does by default for the reference's device code; the chunk
 // hand-over and the cost tree re-associate anyway, so its results are the same few-ulp
 // class either way (tests state the bound).
+//
+// Launch latency: at K = 1e4 the whole kernel is ~15 us, so every dependent memory round trip
+// in the prologue (~1 us each) shows.  What the first instructions need travels BY VALUE in
+// the kernel arguments (RolloutHot: pointers, Philox key/offset, geometry, x0); the rest of the
+// descriptor and the nominal controls are fetched while the Philox blocks are computed, and
+// the only barrier of the prologue sits AFTER noise generation.
 // ------------------------------------------------------------------------------------------
 template <int A>
-struct LaneParams {     // wave-uniform problem constants, deliberately held in VGPRs: as kernel
-    float goal[2 * A];  // arguments they and the launch geometry exceed the 102-SGPR file and
+struct LaneParams {     // wave-uniform problem constants, deliberately held in VGPRs: kept in
+    float goal[2 * A];  // SGPRs they and the launch geometry exceed the 102-SGPR file, and
     float w[2 * A];     // every spilled scalar costs a v_readlane + s_nop in the hot loop
     float sigma[A];
     float dt, B0, dt2;
 };
 
+__device__ __forceinline__ float to_vgpr(float x)
+{   // opaque move: afterwards the compiler no longer knows the value is wave-uniform
+    asm volatile("" : "+v"(x));
+    return x;
+}
 
 template <int A, int NG, bool SAMPLE, int LOGC>
-__device__ __forceinline__ void fused_body(const RolloutArgs& g)
+__device__ __forceinline__ void fused_body(const RolloutHot& h)
 {
     constexpr int SG = Dim<A>::SG;
     constexpr int BPG = Dim<A>::BPG;
     constexpr int NE = NG * BPG * 4;          // normals held per lane
     constexpr int C = 1 << LOGC;
 
+    // everything the tile loop touches is read from the by-value arguments ONCE, up front
+    const int ng = h.ng, nq = h.nq;
+    const int K = h.K, T = h.T, TA = h.TA, NBT = h.NBT, NBTp = h.NBTp;
+    const int c_last = h.c_last, n_last = h.n_last, n_tileblk = h.n_tileblk, L = h.L;
+    const long long k_offset = h.k_offset;
+    const unsigned long long seed = h.seed;
+    float* const Eint = h.Eint;
+    const RolloutArgs& g = *h.rest;           // cold part of the descriptor (device memory)
+
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBTp] U in block layout
-    float4* uclds = ulds + g.NBTp;                               // [NBTp] lambda*inv_s*U
-    float* plds = reinterpret_cast<float*>(uclds + g.NBTp);      // [kParamFloats]
-    const int nq = g.nq;                                         // blocks per lane = ng*BPG
+    float4* uclds = ulds + NBTp;                                 // [NBTp] lambda*inv_s*U
     const int TAp = C * nq * 4;
-    float* wsum = plds + kParamFloats;                           // [4][TAp]
+    float* wsum = reinterpret_cast<float*>(uclds + NBTp);        // [4][TAp]
     float* nrun = wsum + 4 * TAp;                                // [TAp]
     float* misc = nrun + TAp;                                    // [8]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane & (C - 1);
-    const int ng = g.ng;
 
-    // ---- stage U, lambda*inv_s*U and the problem constants in LDS --------------------------
+    // ---- issue the loads of the nominal controls and of the cold constants; they complete
+    //      while the first tile's Philox blocks are computed ----------------------------------
+    const float lambda = g.lambda, inv_lambda = g.inv_lambda;
     {
-        const float* Uin = g.U + (g.solve_idx & 1ull) * g.TA;
-        for (int b = threadIdx.x; b < g.NBTp; b += kRolloutThreads) {
+        const float* Uin = h.U_in;
+        for (int b = threadIdx.x; b < NBTp; b += kRolloutThreads) {
             float u[4], uc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = b * 4 + i;
-                u[i] = (n < g.TA) ? Uin[n] : 0.0f;
-                uc[i] = g.lambda * (u[i] * g.inv_s[(b * 4 + i) % A]);
+                u[i] = (n < TA) ? Uin[n] : 0.0f;
+                uc[i] = lambda * (u[i] * g.inv_s[(b * 4 + i) % A]);
             }
             ulds[b] = make_float4(u[0], u[1], u[2], u[3]);
             uclds[b] = make_float4(uc[0], uc[1], uc[2], uc[3]);
         }
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int i = 0; i < 2 * A; ++i) {
-                plds[i] = g.goal[i];
-                plds[8 + i] = g.w[i];
-                plds[16 + i] = g.dev->x0[i];
-            }
-#pragma unroll
-            for (int i = 0; i < A; ++i) plds[24 + i] = g.sigma[i];
-            plds[28] = g.dt;
-            plds[29] = g.B0;
-        }
     }
-    __syncthreads();
     LaneParams<A> P;
     float x0p[A], x0v[A];
 #pragma unroll
-    for (int i = 0; i < 2 * A; ++i) { P.goal[i] = plds[i]; P.w[i] = plds[8 + i]; }
+    for (int i = 0; i < 2 * A; ++i) { P.goal[i] = to_vgpr(g.goal[i]); P.w[i] = to_vgpr(g.w[i]); }
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        P.sigma[i] = plds[24 + i];
-        x0p[i] = plds[16 + i];
-        x0v[i] = plds[16 + A + i];
+        P.sigma[i] = to_vgpr(g.sigma[i]);
+        x0p[i] = to_vgpr(h.x0[i]);
+        x0v[i] = to_vgpr(h.x0[A + i]);
     }
-    P.dt = plds[28];
-    P.B0 = plds[29];
+    P.dt = to_vgpr(g.dt);
+    P.B0 = to_vgpr(g.B0);
     P.dt2 = P.dt * P.dt;
+    const long long k_cover = g.k_cover;
+    float* const cost_out = g.cost;
 
     // chunk geometry of this lane (same for every tile group)
-    const int L = g.L;                                         // steps per full chunk
-    const int ns_own = (c < g.c_last) ? L : (c == g.c_last ? g.n_last : 0);
-    const int nbefore = min(c * L, g.T);
-    const unsigned long long blk0 = g.solve_idx * (unsigned long long)g.NBT
+    const int ns_own = (c < c_last) ? L : (c == c_last ? n_last : 0);
+    const int nbefore = min(c * L, T);
+    const unsigned long long blk0 = h.solve_idx * (unsigned long long)NBT
                                     + (unsigned long long)(c * nq);
     const float Lm1 = (float)(L - 1);
 
     RunState rs{INFINITY, 0.0f};
     bool first = true;
 
-    for (int tb = blockIdx.x; tb < g.n_tileblk; tb += gridDim.x) {
+    for (int tb = blockIdx.x; tb < n_tileblk; tb += gridDim.x) {
         const long long gid = (long long)tb * kRolloutThreads + threadIdx.x;
         const long long kloc = gid >> LOGC;
-        const bool valid = kloc < g.K;
-        const unsigned long long kglob = (unsigned long long)(g.k_offset + kloc);
+        const bool valid = kloc < K;
+        const unsigned long long kglob = (unsigned long long)(k_offset + kloc);
         const size_t tile = (size_t)(gid >> 6);
-        float* etile = g.Eint + ((tile * nq) * 64 + lane) * 4;    // + q*256 floats per block
+        float* etile = Eint + ((tile * nq) * 64 + lane) * 4;      // + q*256 floats per block
 
-        // ---- pass 1: draw (or load) the chunk's noise into registers and store it; the
-        //      chunk's zero-state response is two weighted sums of a = u + e:
-        //      V = dt*S1,  P = B0*S1 + dt^2*((L-1)*S1 - S2),  S1 = sum a_j, S2 = sum j*a_j.
-        //      No masking: what a partial or empty chunk adds past the horizon is not used. ---
+        // ---- pass 1a: draw (or load) the chunk's noise into registers and store it ----------
         float e[NE];
-        float S1[A], S2[A];
-#pragma unroll
-        for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
 #pragma unroll
             for (int i = 0; i < BPG * 4; ++i) e[gi * BPG * 4 + i] = 0.f;
             if (gi < ng) {
-                float u[BPG * 4];
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
                     const int q = gi * BPG + j;
                     float* eq = &e[q * 4];
                     if constexpr (SAMPLE) {
-                        const uint4 r = PhiloxAt::block(blk0 + (unsigned long long)q, kglob, g.seed);
+                        const uint4 r = PhiloxAt::block(blk0 + (unsigned long long)q, kglob, seed);
                         float z[4];
                         box_muller_hw(r.x, r.y, z[0], z[1]);
                         box_muller_hw(r.z, r.w, z[2], z[3]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
-                        if (c * nq + q < g.NBT)      // blocks past the horizon are not stored
+                        if (c * nq + q < NBT)      // blocks past the horizon are not stored
                             *reinterpret_cast<float4*>(etile + (size_t)q * 256) =
                                 make_float4(eq[0], eq[1], eq[2], eq[3]);
                     } else {
                         const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
                         eq[0] = t.x; eq[1] = t.y; eq[2] = t.z; eq[3] = t.w;
                     }
-                    const float4 u4 = ulds[c * nq + q];
+                }
+            }
+        }
+        if (first) __syncthreads();      // U and lambda*inv_s*U are in LDS from here on
+
+        // ---- pass 1b: the chunk's zero-state response is two weighted sums of a = u + e:
+        //      V = dt*S1,  P = B0*S1 + dt^2*((L-1)*S1 - S2),  S1 = sum a_j, S2 = sum j*a_j.
+        //      No masking: what a partial or empty chunk adds past the horizon is not used. ---
+        float S1[A], S2[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi < ng) {
+                float u[BPG * 4];
+#pragma unroll
+                for (int j = 0; j < BPG; ++j) {
+                    const float4 u4 = ulds[c * nq + gi * BPG + j];
                     u[j * 4 + 0] = u4.x; u[j * 4 + 1] = u4.y; u[j * 4 + 2] = u4.z; u[j * 4 + 3] = u4.w;
                 }
 #pragma unroll
@@ -248,7 +265,7 @@ __device__ __forceinline__ void fused_body(const RolloutArgs& g)
                         r = fmaf(d * P.w[A + i], d, r);
                     }
                     cpart += r;
-                    if (sl + 1 == g.n_last) {                  // wave-uniform
+                    if (sl + 1 == n_last) {                  // wave-uniform
                         cT = cpart;
 #pragma unroll
                         for (int i = 0; i < A; ++i) { pT[i] = p[i]; vT[i] = v[i]; }
@@ -268,57 +285,76 @@ __device__ __forceinline__ void fused_body(const RolloutArgs& g)
                 const float d = vT[i] - P.goal[A + i];
                 fc = fmaf(d * P.w[A + i], d, fc);
             }
-            cpart = (c < g.c_last) ? cpart : (c == g.c_last ? cT + fc : 0.0f);
+            cpart = (c < c_last) ? cpart : (c == c_last ? cT + fc : 0.0f);
         }
         const float cost = group_sum<LOGC>(cpart);
-        if (valid && c == 0) g.cost[kloc] = cost;
+        if (valid && c == 0) cost_out[kloc] = cost;
 
         // ---- block tail: min, exp weights, weighted noise sums ----------------------------
         const float m_t = tile_min(valid ? cost : INFINITY, misc, wave, lane);
-        const float wt = valid ? expf(-g.inv_lambda * (cost - m_t)) : 0.0f;
+        const float wt = valid ? expf(-inv_lambda * (cost - m_t)) : 0.0f;
         {
             const float sw = wave_sum(c == 0 ? wt : 0.0f);
             if (lane == 0) misc[4 + wave] = sw;
         }
-        const float wtN = ((long long)kglob < g.k_cover) ? wt : 0.0f;
-        float* wrow = wsum + wave * TAp + (lane * nq) * 4;       // valid for lane < C
+        const float wtN = ((long long)kglob < k_cover) ? wt : 0.0f;
+        // one float4 LDS store per Philox block from the first C lanes
+        float4* wrow = reinterpret_cast<float4*>(wsum + wave * TAp + (c * nq) * 4);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (gi < ng) {
 #pragma unroll
-                for (int i = 0; i < BPG * 4; ++i) {
-                    const float val = strided_sum<LOGC>(wtN * e[gi * BPG * 4 + i]);
-                    if (lane < C) wrow[gi * BPG * 4 + i] = val;
+                for (int j = 0; j < BPG; ++j) {
+                    const int q = gi * BPG + j;
+                    float sv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        sv[i] = symmetric_strided_sum<LOGC>(wtN * e[q * 4 + i]);
+                    if (lane < C) wrow[q] = make_float4(sv[0], sv[1], sv[2], sv[3]);
                 }
             }
         }
         __syncthreads();
-        fold_tile(rs, m_t, misc, wsum, nrun, TAp, g.TA, g.inv_lambda, first);
+        fold_tile(rs, m_t, misc, wsum, nrun, TAp, TA, inv_lambda, first);
         first = false;
         __syncthreads();
     }
 
     // ---- publish the block partial ----------------------------------------------------------
-    float* Nout = g.part_N + (size_t)blockIdx.x * g.TA;
-    for (int n = threadIdx.x; n < g.TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
+    float* Nout = g.part_N + (size_t)blockIdx.x * TA;
+    for (int n = threadIdx.x; n < TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
     if (threadIdx.x == 0) {
         g.part_m[blockIdx.x] = rs.M;
         g.part_s[blockIdx.x] = rs.S;
     }
 }
 
-template <int A, int NG, bool SAMPLE>
-__global__ void __launch_bounds__(kRolloutThreads)
-k_rollout_fused(const RolloutArgs g)
+// Occupancy target: the kernel is VALU-issue / latency bound, so 4 waves per SIMD (<= 128 VGPRs)
+// where the register-resident noise leaves room; forcing it on larger chunks spills
+// (measured: -35 %), so those keep hipcc's own allocation.
+template <int A, int NG>
+constexpr int fused_min_waves()
 {
-    switch (g.logC) {      // wave-uniform: one specialised body per lanes-per-trajectory
-        case 0: fused_body<A, NG, SAMPLE, 0>(g); break;
-        case 1: fused_body<A, NG, SAMPLE, 1>(g); break;
-        case 2: fused_body<A, NG, SAMPLE, 2>(g); break;
-        case 3: fused_body<A, NG, SAMPLE, 3>(g); break;
-        case 4: fused_body<A, NG, SAMPLE, 4>(g); break;
-        case 5: fused_body<A, NG, SAMPLE, 5>(g); break;
-        default: fused_body<A, NG, SAMPLE, 6>(g); break;
+    constexpr int NE = NG * Dim<A>::BPG * 4;
+    return NE <= 32 ? 4 : 2;
+}
+
+template <int A, int NG, bool SAMPLE>
+__global__ void __launch_bounds__(kRolloutThreads, (fused_min_waves<A, NG>()))
+k_rollout_fused(const RolloutHot h)
+{
+#ifdef MPPI_ONLY_LOGC          // analysis builds: a single body, for reading the ISA
+    fused_body<A, NG, SAMPLE, MPPI_ONLY_LOGC>(h);
+    return;
+#endif
+    switch (h.logC) {      // wave-uniform: one specialised body per lanes-per-trajectory
+        case 0: fused_body<A, NG, SAMPLE, 0>(h); break;
+        case 1: fused_body<A, NG, SAMPLE, 1>(h); break;
+        case 2: fused_body<A, NG, SAMPLE, 2>(h); break;
+        case 3: fused_body<A, NG, SAMPLE, 3>(h); break;
+        case 4: fused_body<A, NG, SAMPLE, 4>(h); break;
+        case 5: fused_body<A, NG, SAMPLE, 5>(h); break;
+        default: fused_body<A, NG, SAMPLE, 6>(h); break;
     }
 }
 
@@ -327,12 +363,13 @@ hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream
                           LaunchTiming tm)
 {
     const size_t lds = rollout_lds_bytes(a.NBTp, a.C * a.nq * 4);
+    const RolloutHot h = make_hot(a);
     if (sample)
         MPPI_LAUNCH((k_rollout_fused<A, NG, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
-                    a);
+                    h);
     else
         MPPI_LAUNCH((k_rollout_fused<A, NG, false>), dim3(grid), dim3(kRolloutThreads), lds, st,
-                    tm, a);
+                    tm, h);
     return hipGetLastError();
 }
 
@@ -360,6 +397,5 @@ hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
         }
     }
 }
-
 
 }  // namespace mppi

@@ -3,7 +3,7 @@
 import re, sys, collections
 lines = open(sys.argv[1]).read().splitlines()
 key = sys.argv[2]
-start = next(i for i, l in enumerate(lines) if l.startswith('_ZN') and key in l and l.rstrip().split(':')[0].endswith('E') )
+start = next(i for i, l in enumerate(lines) if l.startswith('_ZN') and key in l and l.rstrip().split(':')[0][-1] in 'Ey' )
 end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
 ops = collections.Counter()
 for l in lines[start + 1:end]:
