@@ -33,6 +33,7 @@ WORKLOADS = {
     "c4": (3, 125_000, 200, "point_mass3d K=1e6/8 per GPU T=200 (BASELINE configs[3] shard)"),
     "c1": (1, 100, 50, "point_mass1d K=100 T=50 (BASELINE configs[0] shape, on the GPU)"),
     "floor": (2, 10_000, 8, "launch-floor probe: 2-D K=1e4 T=8 (not a BASELINE config)"),
+    "c4full": (3, 1_000_000, 200, "point_mass3d K=1e6 T=200 on ONE GPU (BASELINE configs[3] unsharded)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdint>
+#include <cstdlib>
 
 namespace mppi {
 
@@ -91,6 +92,10 @@ inline RolloutHot make_hot(const RolloutArgs& a)
     h.logC = a.logC; h.ng = a.ng; h.nq = a.nq; h.L = a.L;
     h.c_last = a.c_last; h.n_last = a.n_last; h.n_tileblk = a.n_tileblk;
     for (int i = 0; i < 8; ++i) h.x0[i] = a.x0[i];
+    if (const char* dbg = getenv("MPPI_DEBUG_SKIP")) {   // latency probes, never set in production
+        h.n_tileblk = 0;                                 // 1: prologue + epilogue only
+        if (dbg[0] == '2') { h.NBTp = 0; h.TA = 0; }     // 2: (almost) empty kernel
+    }
     return h;
 }
 
