@@ -1,0 +1,109 @@
+// mppi_closed_loop.cpp -- the closed-loop driver of the reference (src/main.cu:220-399) on the
+// MI355X engine and the stand-in plant: get_u -> get_act (timed) -> env.simulate -> env.get_x ->
+// set_x, until the plant's episode ends; prints the reference's "Average controller execution
+// time" and writes the trajectory CSV in the reference's column format (src/main.cu:32-57) for
+// 2-D, generalised to A axes.  BASELINE config 5: point_mass3d, K=1e5, T=200, 100 Hz re-plan ->
+// the solve must fit 10 ms.
+//
+//   mppi_closed_loop [--dims A] [--samples K] [--horizon T] [--dt 0.1] [--model file.xml]
+//                    [--seconds S] [--traj out.csv] [--lambda L] [--noise SIGMA]
+// (the reference reads these from YAML via yaml-cpp/TCLAP, which this image lacks; the keys are
+// the same: samples, horizon, dt, lambda, noise, goal/cost.w take the shipped config values)
+#include "mppi_env.hpp"
+#include "point_mass.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+static void to_csv_traj(const std::string& filename, const std::vector<std::vector<float>>& x,
+                        const std::vector<std::vector<float>>& u, int A)
+{
+    std::ofstream out(filename);
+    const char* ax[4] = {"x", "y", "z", "w"};
+    for (int i = 0; i < A; ++i) out << ax[i] << ",";
+    for (int i = 0; i < A; ++i) out << "v" << ax[i] << ",";
+    for (int i = 0; i < A; ++i) out << "u" << ax[i] << ",";
+    out << "size_x,size_u\n";
+    for (size_t r = 0; r < x.size(); ++r) {
+        for (float v : x[r]) out << v << ",";
+        if (r < u.size())
+            for (float v : u[r]) out << v << ",";
+        if (r == 0) out << x.size() << "," << u.size();
+        out << "\n";
+    }
+}
+
+int main(int argc, char** argv)
+{
+    int A = 3, K = 100000, T = 200;
+    float dt = 0.1f, lambda = 1.0f, sigma = 0.025f;
+    double seconds = 2.0;
+    std::string model, traj;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        std::string k = argv[i], v = argv[i + 1];
+        if (k == "--dims") A = atoi(v.c_str());
+        else if (k == "--samples") K = atoi(v.c_str());
+        else if (k == "--horizon") T = atoi(v.c_str());
+        else if (k == "--dt") dt = (float)atof(v.c_str());
+        else if (k == "--model") model = v;
+        else if (k == "--seconds") seconds = atof(v.c_str());
+        else if (k == "--traj") traj = v;
+        else if (k == "--lambda") lambda = (float)atof(v.c_str());
+        else if (k == "--noise") sigma = (float)atof(v.c_str());
+        else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    const int S = 2 * A;
+    // goal / cost.w of the shipped configs (reference config/point_mass{1,2,3}d.yaml)
+    const float goals[4][8] = {{1, 0}, {1, 0, 0, 0}, {1, .5f, .75f, 0, 0, 0}, {1, .5f, .75f, .25f}};
+    const float ws[4][8] = {{1, 5}, {1, 1, 50, 50}, {1, 1, 1, 5, 5, 5}, {1, 1, 1, 1, 5, 5, 5, 5}};
+    std::vector<float> goal(goals[A - 1], goals[A - 1] + S), w(ws[A - 1], ws[A - 1] + S);
+
+    std::string axes(1, (char)('0' + A));
+    PointMassEnv env(model.empty() ? axes.c_str() : model.c_str(), nullptr, false);
+    env.set_end_time(seconds);
+    std::cout << env << std::endl;
+    if (env.dims() != A) { fprintf(stderr, "model has %d axes, --dims %d\n", env.dims(), A); return 2; }
+
+    PointMassModel* model_ctl = new PointMassModel(K, T, dt, S, A, false);
+    std::vector<float> sig(A, sigma);
+    model_ctl->set_params(lambda, sig.data(), nullptr);
+    std::vector<float> x(S), U(T * A, 0.0f), next_act(A), u_prev(T * A);
+    env.get_x(x.data());
+    model_ctl->memcpy_set_data(x.data(), U.data(), goal.data(), w.data());
+
+    std::vector<std::vector<float>> xs{x}, us;
+    double ctl_ms = 0.0, worst_ms = 0.0;
+    size_t t = 0;
+    bool done = false;
+    while (!done) {
+        model_ctl->get_u(u_prev.data());
+        auto t1 = std::chrono::steady_clock::now();
+        model_ctl->get_act(next_act.data());
+        auto t2 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        ctl_ms += ms;
+        if (t > 0 && ms > worst_ms) worst_ms = ms;      // first call includes one-off set-up
+        done = env.simulate(next_act.data());
+        env.get_x(x.data());
+        us.push_back(next_act);
+        xs.push_back(x);
+        model_ctl->set_x(x.data());
+        ++t;
+    }
+    double dist = 0;
+    for (int i = 0; i < A; ++i) dist += (x[i] - goal[i]) * (x[i] - goal[i]);
+    std::cout << "Average controller execution time: " << ctl_ms / t << std::endl;
+    std::cout << "T: " << t << std::endl;
+    std::cout << "Delta: " << ctl_ms << std::endl;
+    printf("RESULT steps=%zu avg_ms=%.4f worst_ms=%.4f final_dist=%.4f budget_ms=10\n", t,
+           ctl_ms / t, worst_ms, std::sqrt(dist));
+    if (!traj.empty()) to_csv_traj(traj, xs, us, A);
+    delete model_ctl;
+    return 0;
+}

@@ -1,0 +1,97 @@
+"""Stand-in plant and the closed-loop driver (BASELINE config 5)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+INC = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(ROOT, "mppi_gpu_amd", "lib")
+
+
+def _cc(src, exe):
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", INC, src, "-o", exe, "-L", LIBDIR,
+                        "-lmppi_gpu_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+MJCF = """<mujoco model="T">
+  <default>
+    <joint armature="0.02" damping="0.2" limited="true"/>
+    <motor ctrllimited="true" ctrlrange="-0.5 0.75" />
+  </default>
+  <option gravity="0 0 0" integrator="RK4" timestep="0.005"/>
+  <worldbody><body name="agent" pos="0 0 .05">
+    <joint axis="1 0 0" name="agent_x" pos="0 0 0" range="-0.3 0.3" stiffness="0" type="slide"/>
+    <joint axis="0 1 0" name="agent_y" pos="0 0 0" range="-0.3 0.3" stiffness="0" type="slide"/>
+    <joint axis="0 0 1" name="agent_z" pos="0 0 0" range="-0.3 0.3" stiffness="0" type="slide"/>
+    <geom conaffinity="1" contype="1" name="agent" pos="0 0 0" size=".1" type="sphere"/>
+  </body></worldbody>
+  <actuator><motor gear="4.0" joint="agent_x"/></actuator>
+</mujoco>
+"""
+
+
+def test_stand_in_plant_physics_and_mjcf_scan(tmp_path):
+    exe = _cc(os.path.join(ROOT, "tests", "cpp", "env_check.cpp"), str(tmp_path / "env_check"))
+    # defaults of the shipped scenes: 2 axes, dt 0.01, armature 0.01, damping 0.1, gear 10, r=.05
+    out = subprocess.run([exe, "2"], capture_output=True, text=True, check=True).stdout
+    assert "2 slide axes" in out and "dt 0.01" in out and "gear 10" in out
+    M = 1000 * 4 / 3 * np.pi * 0.05 ** 3 + 0.01
+    x3 = np.array(re.search(r"STEP3 (.*)", out).group(1).split(), float)
+
+    def closed_form(u, t, gear=10.0, damp=0.1, m=M):
+        f = gear * u
+        v = f / damp * (1 - np.exp(-damp * t / m))
+        q = f / damp * (t - m / damp * (1 - np.exp(-damp * t / m)))
+        return q, v
+    q, v = closed_form(0.5, 0.03)
+    assert np.isclose(x3[0], q, rtol=1e-5) and np.isclose(x3[2], v, rtol=1e-5)
+    q, v = closed_form(-1.0, 0.03)                     # u = -2 is clamped to the control range
+    assert np.isclose(x3[1], q, rtol=1e-5) and np.isclose(x3[3], v, rtol=1e-5)
+    # simulate() advances 1/60 s per call (two 0.01 s steps) until the episode end
+    frames = int(re.search(r"FRAMES (\d+)", out).group(1))
+    assert frames == 49                                 # (1.0 - 0.03) / 0.02 rounded up
+    end = np.array(re.search(r"END (.*)", out).group(1).split(), float)
+    assert end[0] == pytest.approx(1.4) and end[2] == 0.0      # joint range reached, stopped
+    # parameters are read from an MJCF file when given one
+    p = tmp_path / "scene.xml"
+    p.write_text(MJCF)
+    out = subprocess.run([exe, str(p)], capture_output=True, text=True, check=True).stdout
+    assert "3 slide axes" in out and "dt 0.005" in out and "armature 0.02" in out
+    assert "damping 0.2" in out and "gear 4" in out
+    m2 = 1000 * 4 / 3 * np.pi * 0.1 ** 3 + 0.02
+    x3 = np.array(re.search(r"STEP3 (.*)", out).group(1).split(), float)
+    q, v = closed_form(0.5, 0.015, gear=4.0, damp=0.2, m=m2)
+    assert np.isclose(x3[0], q, rtol=1e-5) and np.isclose(x3[3], v, rtol=1e-5)
+    q, v = closed_form(-0.5, 0.015, gear=4.0, damp=0.2, m=m2)     # clamp at ctrlrange[0]
+    assert np.isclose(x3[1], q, rtol=1e-5)
+
+
+def test_closed_loop_driver_builds():
+    _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), os.path.join(ROOT, "apps", "mppi_closed_loop"))
+
+
+@pytest.mark.gpu
+def test_closed_loop_config5_meets_100hz_budget(gpu, tmp_path):
+    """BASELINE config 5: point_mass3d, K=1e5, T=200 in closed loop with the stand-in plant;
+    every re-plan must fit the 10 ms (100 Hz) budget and the mass must approach the goal."""
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    traj = tmp_path / "traj.csv"
+    out = subprocess.run([exe, "--dims", "3", "--samples", "100000", "--horizon", "200",
+                          "--seconds", "1.5", "--traj", str(traj)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"RESULT steps=(\d+) avg_ms=(\S+) worst_ms=(\S+) final_dist=(\S+)", out.stdout)
+    steps, avg_ms, worst_ms, dist = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert steps in (75, 76)           # the call that reports "done" is counted too
+    assert avg_ms < 10.0 and worst_ms < 10.0, out.stdout
+    d0 = np.sqrt(1 + 0.25 + 0.75 ** 2)
+    assert dist < 0.8 * d0, f"did not approach the goal: {dist} vs {d0}"
+    assert "Average controller execution time" in out.stdout
+    rows = traj.read_text().strip().splitlines()
+    assert rows[0].startswith("x,y,z,vx,vy,vz,ux,uy,uz,size_x,size_u") and len(rows) == steps + 2, len(rows)
