@@ -5,10 +5,11 @@
 // 2-D, generalised to A axes.  BASELINE config 5: point_mass3d, K=1e5, T=200, 100 Hz re-plan ->
 // the solve must fit 10 ms.
 //
-//   mppi_closed_loop [--dims A] [--samples K] [--horizon T] [--dt 0.1] [--model file.xml]
+//   mppi_closed_loop [-c config.yaml] [--dims A] [--samples K] [--horizon T] [--dt 0.1] [--model file.xml]
 //                    [--seconds S] [--traj out.csv] [--lambda L] [--noise SIGMA]
-// (the reference reads these from YAML via yaml-cpp/TCLAP, which this image lacks; the keys are
-// the same: samples, horizon, dt, lambda, noise, goal/cost.w take the shipped config values)
+// -c reads a configuration file with the reference's keys (include/mppi_config.hpp); options
+// given after it override single values (the reference's -c/--config, src/main.cu:401-453))
+#include "mppi_config.hpp"
 #include "mppi_env.hpp"
 #include "point_mass.hpp"
 
@@ -45,9 +46,21 @@ int main(int argc, char** argv)
     float dt = 0.1f, lambda = 1.0f, sigma = 0.025f;
     double seconds = 2.0;
     std::string model, traj;
+    std::vector<float> cfg_goal, cfg_w, cfg_init;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
-        if (k == "--dims") A = atoi(v.c_str());
+        if (k == "-c" || k == "--config") {
+            MppiConfig cfg;
+            if (!cfg.parse_file(v) || !cfg.consistent()) {
+                fprintf(stderr, "config error: %s\n", cfg.error.c_str());
+                return 1;
+            }
+            A = cfg.act_dim; K = cfg.samples; T = cfg.horizon; dt = cfg.dt; lambda = cfg.lambda;
+            // the shipped files carry noise 0.25 while the reference's effective sigma is its
+            // hard-coded 0.025; --noise overrides explicitly
+            cfg_goal = cfg.goal; cfg_w = cfg.cost_w; cfg_init = cfg.init_act;
+            if (model.empty()) model = cfg.env;
+        } else if (k == "--dims") A = atoi(v.c_str());
         else if (k == "--samples") K = atoi(v.c_str());
         else if (k == "--horizon") T = atoi(v.c_str());
         else if (k == "--dt") dt = (float)atof(v.c_str());
@@ -63,6 +76,7 @@ int main(int argc, char** argv)
     const float goals[4][8] = {{1, 0}, {1, 0, 0, 0}, {1, .5f, .75f, 0, 0, 0}, {1, .5f, .75f, .25f}};
     const float ws[4][8] = {{1, 5}, {1, 1, 50, 50}, {1, 1, 1, 5, 5, 5}, {1, 1, 1, 1, 5, 5, 5, 5}};
     std::vector<float> goal(goals[A - 1], goals[A - 1] + S), w(ws[A - 1], ws[A - 1] + S);
+    if (!cfg_goal.empty()) { goal = cfg_goal; w = cfg_w; }
 
     std::string axes(1, (char)('0' + A));
     PointMassEnv env(model.empty() ? axes.c_str() : model.c_str(), nullptr, false);
@@ -74,6 +88,9 @@ int main(int argc, char** argv)
     std::vector<float> sig(A, sigma);
     model_ctl->set_params(lambda, sig.data(), nullptr);
     std::vector<float> x(S), U(T * A, 0.0f), next_act(A), u_prev(T * A);
+    if (!cfg_init.empty())          // reference init_action_seq, src/main.cu:678-684
+        for (int t = 0; t < T; ++t)
+            for (int a = 0; a < A; ++a) U[t * A + a] = cfg_init[a];
     env.get_x(x.data());
     model_ctl->memcpy_set_data(x.data(), U.data(), goal.data(), w.data());
 
