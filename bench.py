@@ -147,7 +147,7 @@ def main():
         ab = algorithmic_bytes_rollout(K, T, A)
         ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # PMC traffic cannot be collected from inside the timed process: it comes from the
-        # committed rocprofv3 --pmc summary of this workload/geometry (tools_traffic.sh), if any
+        # committed rocprofv3 --pmc summary of this workload/geometry (tools/traffic.sh), if any
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))

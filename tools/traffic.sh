@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_traffic.sh <tag> <bench args...>
+# usage: tools/traffic.sh <tag> <bench args...>
 # HBM traffic of the rollout kernel from the TCC counters, one counter per pass
 # (guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 # reports half the bytes of a wide coalesced read -> doubled here; WRITE_SIZE is exact for
