@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
+    ap.add_argument("--inject", action="store_true",
+                    help="ANALYSIS ONLY: injected-noise mode (no sampling); not a valid bench result")
     ap.add_argument("--event-every", type=int, default=8,
                     help="record HIP events around the kernels of every n-th timed solve")
     args = ap.parse_args()
@@ -114,6 +116,8 @@ def main():
     m.set_seed(0)
     m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
     geo = m.geometry()
+    if args.inject:
+        m.set_noise(np.zeros((K, T, A), np.float32))
     step = m.solve_async if sharded is None else sharded.solve_async
 
     def fence():
@@ -169,7 +173,7 @@ def main():
             "value": value, "unit": "rollouts/s", "n_gpus": N, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_s / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.inject else "INVALID: injected zero noise (analysis run)",
             "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
                        "global_rollouts": N * K, "sharding": f"samples x{N}",
                        "geometry": geo, "rollout_steps_per_s": value * T},

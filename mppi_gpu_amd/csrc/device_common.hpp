@@ -131,20 +131,24 @@ __device__ __forceinline__ float symmetric_strided_sum(float x)
     return x;
 }
 
-// value of lane (lane - D) within the aligned group of 2^LOGC lanes; caller masks c < D.
-// Groups of <= 16 lanes lie inside one DPP row (row_shr); wider groups cross rows and go
-// through ds_bpermute.
-template <int D, int LOGC>
-__device__ __forceinline__ float lane_up(float x)
+// DPP moves used by the chunk scan (all verified on gfx950 by tools/dpp_probe):
+//   row_shr:D      lane i <- lane i-D inside its 16-lane row (0 shifted in)
+//   row_bcast:15   rows 1 and 3 <- lane 15 of the row below     (row_mask 0xA)
+//   row_bcast:31   rows 2 and 3 <- lane 31                      (row_mask 0xC)
+//   wave_shr:1     lane i <- lane i-1 across the whole wave
+constexpr int kRowBcast15 = 0x142;
+constexpr int kRowBcast31 = 0x143;
+constexpr int kWaveShr1 = 0x138;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows(float x)
 {
-    if constexpr (D < 16 && LOGC <= 4) return dpp<MPPI_ROW_SHR(D)>(x);
-    else return __shfl_up(x, D, 1 << LOGC);
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, false));
 }
-template <int D, int LOGC>
-__device__ __forceinline__ int lane_up_i(int x)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_rows_i(int x)
 {
-    if constexpr (D < 16 && LOGC <= 4) return dppi<MPPI_ROW_SHR(D)>(x);
-    else return __shfl_up(x, D, 1 << LOGC);
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false);
 }
 
 // One Euler step of the double integrator, reference src/point_mass_gpu.cu:97-106 with

@@ -179,18 +179,20 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         }
 
         // ---- affine scan over the C chunks: (n, P, V) o (n', P', V') =
-        //      (n + n', P + n'*dt*V + P', V + V') ------------------------------------------
+        //      (n + n', P + n'*dt*V + P', V + V').  All DPP: row_shr inside the 16-lane rows,
+        //      then row_bcast:15 / row_bcast:31 carry the row totals across (C = 32, 64). ----
         {
             int nacc = ns_own;
-#define MPPI_SCAN_LEVEL(D)                                                          \
-            if constexpr (C > (D)) {                                                \
-                const int nl = lane_up_i<(D), LOGC>(nacc);                          \
+            const int cr = (LOGC <= 4) ? c : (lane & 15);      // position inside the DPP row
+#define MPPI_COMBINE(COND, GETF, GETI)                                              \
+            {                                                                       \
+                const int nl = GETI(nacc);                                          \
                 float Pl[A], Vl[A];                                                 \
                 _Pragma("unroll") for (int i = 0; i < A; ++i) {                     \
-                    Pl[i] = lane_up<(D), LOGC>(Pz[i]);                              \
-                    Vl[i] = lane_up<(D), LOGC>(Vz[i]);                              \
+                    Pl[i] = GETF(Pz[i]);                                            \
+                    Vl[i] = GETF(Vz[i]);                                            \
                 }                                                                   \
-                if (c >= (D)) {                                                     \
+                if (COND) {                                                         \
                     const float tau = (float)nacc * P.dt;                           \
                     _Pragma("unroll") for (int i = 0; i < A; ++i) {                 \
                         Pz[i] = fmaf(tau, Vl[i], Pl[i]) + Pz[i];                    \
@@ -199,13 +201,15 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
                     nacc += nl;                                                     \
                 }                                                                   \
             }
-            MPPI_SCAN_LEVEL(1)
-            MPPI_SCAN_LEVEL(2)
-            MPPI_SCAN_LEVEL(4)
-            MPPI_SCAN_LEVEL(8)
-            MPPI_SCAN_LEVEL(16)
-            MPPI_SCAN_LEVEL(32)
-#undef MPPI_SCAN_LEVEL
+            if constexpr (C > 1) MPPI_COMBINE(cr >= 1, dpp<MPPI_ROW_SHR(1)>, dppi<MPPI_ROW_SHR(1)>)
+            if constexpr (C > 2) MPPI_COMBINE(cr >= 2, dpp<MPPI_ROW_SHR(2)>, dppi<MPPI_ROW_SHR(2)>)
+            if constexpr (C > 4) MPPI_COMBINE(cr >= 4, dpp<MPPI_ROW_SHR(4)>, dppi<MPPI_ROW_SHR(4)>)
+            if constexpr (C > 8) MPPI_COMBINE(cr >= 8, dpp<MPPI_ROW_SHR(8)>, dppi<MPPI_ROW_SHR(8)>)
+            if constexpr (C > 16)
+                MPPI_COMBINE((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
+            if constexpr (C > 32)
+                MPPI_COMBINE((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
+#undef MPPI_COMBINE
         }
         float p[A], v[A];
         {
@@ -214,8 +218,13 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             for (int i = 0; i < A; ++i) {
                 float Pex = 0.f, Vex = 0.f;
                 if constexpr (C > 1) {
-                    Pex = lane_up<1, LOGC>(Pz[i]);
-                    Vex = lane_up<1, LOGC>(Vz[i]);
+                    if constexpr (LOGC <= 4) {
+                        Pex = dpp<MPPI_ROW_SHR(1)>(Pz[i]);
+                        Vex = dpp<MPPI_ROW_SHR(1)>(Vz[i]);
+                    } else {
+                        Pex = dpp<kWaveShr1>(Pz[i]);
+                        Vex = dpp<kWaveShr1>(Vz[i]);
+                    }
                     if (c == 0) { Pex = 0.f; Vex = 0.f; }
                 }
                 p[i] = fmaf(tau0, x0v[i], x0p[i]) + Pex;
@@ -336,7 +345,7 @@ template <int A, int NG>
 constexpr int fused_min_waves()
 {
     constexpr int NE = NG * Dim<A>::BPG * 4;
-    return NE <= 32 ? 4 : 2;
+    return NE <= 16 ? 4 : 2;
 }
 
 template <int A, int NG, bool SAMPLE>
