@@ -417,6 +417,24 @@ extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&,
 extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
 extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
 
+template <int A>
+int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds);
+extern template int fused_blocks_per_cu_a<1>(int, bool, size_t);
+extern template int fused_blocks_per_cu_a<2>(int, bool, size_t);
+extern template int fused_blocks_per_cu_a<3>(int, bool, size_t);
+extern template int fused_blocks_per_cu_a<4>(int, bool, size_t);
+
+int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds)
+{
+    switch (A) {
+        case 1: return fused_blocks_per_cu_a<1>(NGt, sample, lds);
+        case 2: return fused_blocks_per_cu_a<2>(NGt, sample, lds);
+        case 3: return fused_blocks_per_cu_a<3>(NGt, sample, lds);
+        case 4: return fused_blocks_per_cu_a<4>(NGt, sample, lds);
+        default: return 0;
+    }
+}
+
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
                                 hipStream_t st, LaunchTiming tm)
 {

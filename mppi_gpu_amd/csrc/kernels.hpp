@@ -136,6 +136,7 @@ int rollout_group_blocks(int A);
 int rollout_max_groups(int A);
 int rollout_pick_ng_template(int A, int ng);
 size_t rollout_lds_bytes(int NBTp, int TAp);
+int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds);   // occupancy API, 0 = unknown
 
 // Optional dispatch timing: when both events are non-null the launch goes through
 // hipExtLaunchKernelGGL, which stamps the events with the dispatch packet's own start / end

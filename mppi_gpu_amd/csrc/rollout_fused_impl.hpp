@@ -382,6 +382,44 @@ hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream
     return hipGetLastError();
 }
 
+// resident blocks per CU of the instantiation (occupancy API; used only to size the persistent
+// grid, never for correctness)
+template <int A, int NG>
+int fused_blocks_per_cu_t(bool sample, size_t lds)
+{
+    int n = 0;
+    hipError_t rc = sample
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, true>,
+                                                       kRolloutThreads, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, false>,
+                                                       kRolloutThreads, lds);
+    return rc == hipSuccess ? n : 0;
+}
+
+template <int A>
+int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds)
+{
+    if constexpr (A == 3) {
+        switch (NGt) {
+            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds);
+            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds);
+            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds);
+            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds);
+            default: return 0;
+        }
+    } else {
+        switch (NGt) {
+            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds);
+            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds);
+            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds);
+            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds);
+            case 13: return fused_blocks_per_cu_t<A, 13>(sample, lds);
+            case 20: return fused_blocks_per_cu_t<A, 20>(sample, lds);
+            default: return 0;
+        }
+    }
+}
+
 template <int A>
 hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
                           hipStream_t st, LaunchTiming tm)
