@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (local solve, RCCL all-gather, finish) even "
+                         "with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--inject", action="store_true",
                     help="ANALYSIS ONLY: injected-noise mode (no sampling); not a valid bench result")
     ap.add_argument("--event-every", type=int, default=8,
@@ -97,15 +100,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dist = None
-    if N > 1:
+    if N > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     A, K, T, desc = WORKLOADS[args.workload]
     c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)      # x0 ~ 0.1 N(0,1), U0 = 0, yaml goal/w
 
-    if N == 1:
+    if N == 1 and not args.force_sharded:
         m = PointMassModel(K, T, float(c["dt"]), 2 * A, A)
         sharded = None
     else:

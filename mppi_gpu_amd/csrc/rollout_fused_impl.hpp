@@ -274,8 +274,9 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
                         r = fmaf(d * P.w[A + i], d, r);
                     }
                     cpart += r;
-                    if (sl + 1 == n_last) {                  // wave-uniform
-                        cT = cpart;
+                    if (sl + 1 == n_last) {                  // wave-uniform: keep it a scalar
+                        asm volatile("" ::: "memory");       // branch (hipcc would if-convert it
+                        cT = cpart;                          // into 2A+1 v_cndmask per step)
 #pragma unroll
                         for (int i = 0; i < A; ++i) { pT[i] = p[i]; vT[i] = v[i]; }
                     }
