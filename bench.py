@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="draw each solve's noise one solve ahead inside the combine launch "
+                         "(measured slower; default is in-place sampling)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (local solve, RCCL all-gather, finish) even "
                          "with one rank: rehearsal of the N > 1 path on a one-GPU box")
@@ -118,6 +121,7 @@ def main():
         from mppi_gpu_amd.sharded import ShardedPointMassModel
         sharded = ShardedPointMassModel(N * K, T, float(c["dt"]), 2 * A, A)
         m = sharded.engine          # this rank's shard: samples [rank*K, (rank+1)*K)
+    m.set_pipeline(args.pipeline)
     m.set_tuning(chunks=args.chunks, strict=args.strict, max_blocks=args.max_blocks)
     m.set_seed(0)
     m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])

@@ -104,6 +104,15 @@ int mppi_set_ref_compat(mppi_engine* e, int on);
  * anchor.  max_blocks caps the persistent grid (0 = auto). */
 int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
 
+/* Pipelined noise generation (default OFF): the blocks of solve j's combine launch that are not
+ * needed for combining draw the Philox / Box-Muller noise of solve j+1 into a second buffer; the
+ * rollout of j+1 then reads its noise instead of drawing it.  Same noise values either way (the
+ * stream is a pure function of seed, solve index, sample and time).  Off = the rollout draws its
+ * noise in place.  Measured on MI355X: the stand-alone Philox/Box-Muller
+ * pass costs 7.8 us at K = 1e4 (2-D) -- more than the 5.4 us combine it hides under and more than
+ * the 4.5 us it removes from the rollout -- so in-place sampling is the default. */
+int mppi_set_pipeline(mppi_engine* e, int on);
+
 /* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */
 
 /* Enqueue one full solve on `stream` (a hipStream_t, NULL = the engine's own stream) and

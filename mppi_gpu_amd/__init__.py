@@ -162,6 +162,9 @@ class PointMassModel:
     def set_tuning(self, chunks=0, strict=False, max_blocks=0):
         check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
 
+    def set_pipeline(self, on):
+        check(self._lib.mppi_set_pipeline(self._h, int(bool(on))))
+
     def geometry(self):
         g = (C.c_int * 5)()
         check(self._lib.mppi_get_geometry(self._h, g))

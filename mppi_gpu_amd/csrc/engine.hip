@@ -82,8 +82,13 @@ struct mppi_engine {
     // device memory
     mppi::DevState* d_state = nullptr;
     float* d_U = nullptr;       // 2 x TA
-    float* d_Eint = nullptr;
+    float* d_Eint = nullptr;    // noise buffer 0 (tile layout)
+    float* d_Eint2 = nullptr;   // noise buffer 1 (pipelined mode alternates by solve parity)
     size_t eint_floats = 0;
+    float* last_E = nullptr;    // buffer the last rollout used
+    int pipeline = 0;           // 1 = the combine launch of solve j also draws the noise of j+1
+                                // (measured slower than in-place sampling on MI355X: default off)
+    long long noise_ready_idx = -1;   // solve index whose noise is (being) generated, -1 = none
     float* d_cost = nullptr;
     float *d_pm = nullptr, *d_ps = nullptr, *d_pN = nullptr;
     int part_cap = 0;
@@ -181,7 +186,8 @@ int ensure_geometry(mppi_engine_t* e)
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             ncu = prop.multiProcessorCount;
-        const int per_cu = strict ? 0 : mppi::rollout_blocks_per_cu(e->A, NGt, !e->injected, lds_need);
+        const bool in_kernel_sampling = !e->injected && !e->pipeline;
+        const int per_cu = strict ? 0 : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
         max_blocks = per_cu > 0 ? 3 * per_cu * ncu : 2048;
         if (max_blocks > 3072) max_blocks = 3072;
     }
@@ -198,9 +204,15 @@ int ensure_geometry(mppi_engine_t* e)
         if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
         e->d_Eint = nullptr;
         e->eint_floats = 0;
+        if (e->d_Eint2) HIPCHK(hipFree(e->d_Eint2));
+        e->d_Eint2 = nullptr;
         HIPCHK(hipMalloc(&e->d_Eint, need * sizeof(float)));
+        HIPCHK(hipMalloc(&e->d_Eint2, need * sizeof(float)));
         e->eint_floats = need;
     }
+    e->noise_ready_idx = -1;
+    e->last_E = e->d_Eint;
+    HIPCHK(hipMemsetAsync(e->d_Eint2, 0, e->eint_floats * sizeof(float), e->stream));
     HIPCHK(hipMemsetAsync(e->d_Eint, 0, e->eint_floats * sizeof(float), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (grid > e->part_cap) {
@@ -290,6 +302,20 @@ int prof_pair(mppi_engine_t* e, mppi::LaunchTiming& tm)
     return MPPI_OK;
 }
 
+void fill_gen_args(const mppi_engine_t* e, mppi::GenArgs& ga, unsigned long long idx, float* buf)
+{
+    ga.Eint = buf;
+    ga.seed = e->seed;
+    ga.blk_base = idx * (unsigned long long)e->NBT;
+    ga.k_offset = e->k_offset;
+    ga.n_lanes = (long long)e->n_tileblk * mppi::kRolloutThreads;
+    ga.K = e->K;
+    ga.NBT = e->NBT;
+    ga.logC = e->logC;
+    ga.nq = e->nq;
+    for (int i = 0; i < 4; ++i) ga.sigma[i] = e->sigma[i];
+}
+
 // sampling / rollout / per-block reduction
 int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
 {
@@ -301,14 +327,28 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
         HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, e->C, e->nq, st));
         e->inj_dirty = false;
     }
+    // pipelined mode: the noise of this solve was drawn by the previous solve's combine launch
+    // (or is drawn now by k_generate if nothing was prefetched) into the buffer of this solve's
+    // parity; the rollout runs its no-sampling variant on it.
+    const bool pipelined = e->pipeline && !e->injected && !e->strict;
+    float* Ecur = pipelined ? ((e->solve_idx & 1ull) ? e->d_Eint2 : e->d_Eint) : e->d_Eint;
+    if (pipelined && e->noise_ready_idx != (long long)e->solve_idx) {
+        mppi::GenArgs ga;
+        fill_gen_args(e, ga, e->solve_idx, Ecur);
+        HIPCHK(mppi::launch_generate(e->A, ga, st));
+        e->noise_ready_idx = (long long)e->solve_idx;
+    }
+
     mppi::RolloutArgs ra;
     memset(&ra, 0, sizeof ra);
     fill_rollout_args(e, ra);
+    ra.Eint = Ecur;
     ra.dev_copy = e->d_args;
-    {   // refresh the device copy only when something other than the solve index changed
+    {   // refresh the device copy only when something other than the per-solve fields changed
         mppi::RolloutArgs cmp = ra;
         cmp.solve_idx = 0;
-        for (int i = 0; i < 8; ++i) cmp.x0[i] = 0.f;   // x0 travels by value
+        cmp.Eint = nullptr;                            // travels by value
+        for (int i = 0; i < 8; ++i) cmp.x0[i] = 0.f;   // travels by value
         if (!e->args_valid || memcmp(&cmp, &e->h_args_last, sizeof cmp) != 0) {
             HIPCHK(hipMemcpyAsync(e->d_args, &cmp, sizeof cmp, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -319,10 +359,12 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
     mppi::LaunchTiming tm;
     if ((rc = prof_pair(e, tm))) return rc;
+    const bool sample_in_kernel = !e->injected && !pipelined;
     if (e->strict)
-        HIPCHK(mppi::launch_rollout_stream(e->A, !e->injected, e->grid, ra, st, tm));
+        HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
     else
-        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, !e->injected, e->grid, ra, st, tm));
+        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, sample_in_kernel, e->grid, ra, st, tm));
+    e->last_E = Ecur;
     e->last_C = e->C;
     e->last_nq = e->nq;
     e->last_idx = e->solve_idx;
@@ -332,7 +374,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
 
 int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const float* s,
                     const float* N, long long ms, long long ss, long long Ns, int n_parts,
-                    bool final_mode, float* partial_out)
+                    bool final_mode, float* partial_out, bool prefetch_noise = false)
 {
     if (n_parts < 1 || n_parts > mppi::kMaxParts)
         return fail(MPPI_EINVAL, "n_parts %d out of range", n_parts);
@@ -361,7 +403,16 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
         int rc = prof_pair(e, tm);
         if (rc) return rc;
     }
-    HIPCHK(mppi::launch_combine(ca, st, tm));
+    if (prefetch_noise && e->pipeline && !e->injected && !e->strict && !getenv("MPPI_DEBUG_NOPREFETCH")) {
+        // the blocks this launch does not need for combining draw the NEXT solve's noise
+        mppi::GenArgs ga;
+        const unsigned long long nxt = e->solve_idx + 1ull;
+        fill_gen_args(e, ga, nxt, (nxt & 1ull) ? e->d_Eint2 : e->d_Eint);
+        HIPCHK(mppi::launch_combine(ca, st, tm, &ga, e->A));
+        e->noise_ready_idx = (long long)nxt;
+    } else {
+        HIPCHK(mppi::launch_combine(ca, st, tm));
+    }
     return MPPI_OK;
 }
 
@@ -460,6 +511,7 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_state);
     (void)hipFree(e->d_U);
     (void)hipFree(e->d_Eint);
+    (void)hipFree(e->d_Eint2);
     (void)hipFree(e->d_cost);
     (void)hipFree(e->d_pm);
     (void)hipFree(e->d_ps);
@@ -482,6 +534,7 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
     if (!e || !x0 || !u || !goal || !w) return fail(MPPI_EINVAL, "null argument");
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
+    e->noise_ready_idx = -1;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
     e->have_solve = false;
     HIPCHK(hipMemcpy(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice));
@@ -516,7 +569,8 @@ int mppi_solve_async(mppi_engine* e, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, true, nullptr);
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, true, nullptr,
+                         true);
     if (rc) return rc;
     e->solve_idx += 1;
     e->have_solve = true;
@@ -579,7 +633,7 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     if (noise) {
         const size_t n = (size_t)e->K * e->T * e->A;
         if ((rc = ensure_scratch(e, n))) return rc;
-        HIPCHK(mppi::launch_export_noise(e->A, e->d_Eint, e->d_scratch, e->K, e->T, e->last_C,
+        HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_C,
                                          e->last_nq, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipMemcpy(noise, e->d_scratch, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -590,7 +644,7 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         if ((rc = ensure_scratch(e, n + 8))) return rc;
         float* d_x0 = e->d_scratch + n;
         HIPCHK(hipMemcpy(d_x0, e->x0_last, 8 * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK(mppi::launch_trace_states(e->A, e->d_Eint, e->d_U + (e->last_idx & 1ull) * e->TA,
+        HIPCHK(mppi::launch_trace_states(e->A, e->last_E, e->d_U + (e->last_idx & 1ull) * e->TA,
                                          d_x0, e->d_scratch, e->K, e->T, e->last_C, e->last_nq,
                                          e->dt, e->B0, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -609,7 +663,10 @@ int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const floa
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!(lambda > 0.f)) return fail(MPPI_EINVAL, "lambda must be positive");
     e->lambda = lambda;
-    if (sigma) for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
+    if (sigma) {
+        for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
+        e->noise_ready_idx = -1;            // prefetched noise used the old sigma
+    }
     if (inv_s) for (int i = 0; i < e->A; ++i) e->inv_s[i] = inv_s[i];
     return MPPI_OK;
 }
@@ -618,6 +675,7 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     e->seed = seed;
+    e->noise_ready_idx = -1;
     return MPPI_OK;
 }
 
@@ -661,6 +719,16 @@ int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks)
     return rc;
 }
 
+int mppi_set_pipeline(mppi_engine* e, int on)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pipeline = on ? 1 : 0;
+    e->noise_ready_idx = -1;
+    e->geom_ok = false;         // the occupancy-sized grid depends on the kernel variant
+    return MPPI_OK;
+}
+
 int mppi_partial_len(const mppi_engine* e) { return e ? e->TA + 2 : 0; }
 
 int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
@@ -669,7 +737,8 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, false, d_partial);
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, false, d_partial,
+                         true);
     return rc;
 }
 

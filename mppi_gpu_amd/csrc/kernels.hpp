@@ -119,7 +119,8 @@ struct CombineArgs {
     unsigned int* tickets; // [ceil(TA/64)] arrival counters, zero between launches
     unsigned long long solve_idx;
     int final_mode;
-    int row_splits;        // 0 = auto (8 rows per wave)
+    int row_splits;        // 0 = auto
+    int n_cols, RS;        // filled by the launcher: column blocks and row splits of the grid
 };
 
 constexpr int kRolloutThreads = 256;
@@ -148,9 +149,25 @@ struct LaunchTiming {
 
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
                                 hipStream_t st, LaunchTiming tm = LaunchTiming());
+// Noise generation outside the rollout (pipelined mode): fills one tile-layout buffer with the
+// noise of one solve; identical values to what the fused kernel draws in place.
+struct GenArgs {
+    float* Eint;
+    unsigned long long seed;
+    unsigned long long blk_base;   // solve_idx * NBT
+    long long k_offset;
+    long long n_lanes;             // lanes of the tile layout = tiles * 64 (each draws nq blocks)
+    int K, NBT, logC, nq;
+    float sigma[4];
+};
+hipError_t launch_generate(int A, const GenArgs& g, hipStream_t st);
+
 hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
                                  hipStream_t st, LaunchTiming tm = LaunchTiming());
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming());
+// gen != nullptr: the launch also carries blocks that draw the noise described by *gen
+// (act_dim gen_A) -- the next solve's noise, generated underneath this solve's combine.
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming(),
+                          const GenArgs* gen = nullptr, int gen_A = 0);
 
 // debug / data-movement kernels (off the timed path)
 hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T, int C,

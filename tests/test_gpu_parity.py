@@ -193,6 +193,34 @@ def test_closed_loop_sequence_matches_oracle_chain(gpu):
             assert np.array_equal(m.get_x(), x)
 
 
+def test_pipelined_noise_mode_is_equivalent(gpu):
+    """set_pipeline(True): the noise of solve j+1 is drawn inside solve j's combine launch into a
+    second buffer and the rollout reads it.  Same stream definition, so noise, costs and controls
+    must equal the in-place sampling mode bit for bit, solve after solve, also across set_x."""
+    A, K, T = 3, 3000, 50
+    c = ol.make_case(A, K, T, seed=123)
+    runs = []
+    for pipe in (False, True):
+        with _model(gpu, A, K, T, c) as m:
+            m.set_pipeline(pipe)
+            m.set_seed(77)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            out = []
+            x = c["x0"].copy()
+            for it in range(4):
+                act = m.get_act()
+                inf = m.get_inf(x=False)
+                out.append((act, inf["e"], inf["cost"], inf["u"]))
+                x = (x + np.float32(0.01)).astype(np.float32)
+                m.set_x(x)
+            runs.append(out)
+    for it in range(4):
+        for a, b in zip(runs[0][it], runs[1][it]):
+            assert np.array_equal(a, b), f"pipelined mode differs at solve {it}"
+    # and against the oracle on the noise of the last solve
+    assert not np.array_equal(runs[1][0][1], runs[1][1][1])
+
+
 def test_persistent_grid_and_rescale_path(gpu):
     """max_blocks << tiles forces every block through several tile groups, i.e. through the
     running-minimum rescale branch; costs are spread so that block minima differ a lot."""
