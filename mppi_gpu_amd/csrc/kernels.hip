@@ -196,9 +196,9 @@ k_generate(const GenArgs g)
 // Combine: beta (src/point_mass.cu:273-322), nabla (:328-377), weighted update
 // (:384-480), action read-out and shift (:195-199, :805-824) in one launch.
 //
-// Grid = (ceil(TA/32) column blocks) x (RS row splits), 1024 threads.  Every block recomputes
+// Grid = (ceil(TA/16) column blocks) x (RS row splits), 1024 threads.  Every block recomputes
 // beta and nabla from the (<= kMaxParts) partial minima / exp-sums in a fixed order, then sums
-// ITS rows of the weighted-noise partials for ITS 32 columns, all row loads in flight, two
+// ITS rows of the weighted-noise partials for ITS 16 columns, all row loads in flight, four
 // rows per wave-instruction.  With RS > 1 the splits meet through a per-column-block ticket: each
 // stores its 64 sums, releases at agent scope and takes a ticket; the block that draws the
 // last ticket acquires and adds the RS slabs IN SPLIT ORDER (so the result does not depend on
@@ -238,7 +238,9 @@ k_combine(const CombineArgs a, const GenArgs gen)
         }
     }
     __shared__ float r_lds[kMaxParts];
-    __shared__ float red[32 * kCombineCols];
+    constexpr int RPW = 64 / kCombineCols;            // rows per wave-instruction
+    constexpr int NRG = 16 * RPW;                     // row groups per block
+    __shared__ float red[NRG * kCombineCols];
     __shared__ float scal[32];
     __shared__ int last_flag;
 
@@ -254,9 +256,9 @@ k_combine(const CombineArgs a, const GenArgs gen)
     const int per = (a.n_parts + RS - 1) / RS;
     const int p_begin = rs * per;
     const int p_end = min(a.n_parts, p_begin + per);
-    const int rsub = lane >> 5;                       // two rows per wave-instruction
-    const int rgrp = wave * 2 + rsub;                 // 0..31
-    const int n = cb * kCombineCols + (lane & 31);
+    const int col = lane & (kCombineCols - 1);
+    const int rgrp = wave * RPW + lane / kCombineCols;   // 0..NRG-1
+    const int n = cb * kCombineCols + col;
 
     // ---- every global load this block needs is issued up front: the partial minima and
     //      exp-sums, the first batch of weighted-noise rows and the nominal control; beta,
@@ -271,7 +273,7 @@ k_combine(const CombineArgs a, const GenArgs gen)
     float v[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + 32 * j;
+        const int p = p_begin + rgrp + NRG * j;
         v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
     }
     float uin = 0.0f;
@@ -305,37 +307,37 @@ k_combine(const CombineArgs a, const GenArgs gen)
     float acc = 0.0f;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + 32 * j;
+        const int p = p_begin + rgrp + NRG * j;
         if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
     }
     if (n < a.TA) {      // rows beyond the first batch (only when RS hit its cap)
-        for (int p0 = p_begin + rgrp + 32 * NR; p0 < p_end; p0 += 32 * NR) {
+        for (int p0 = p_begin + rgrp + NRG * NR; p0 < p_end; p0 += NRG * NR) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                const int p = p0 + 32 * j;
+                const int p = p0 + NRG * j;
                 v[j] = (p < p_end) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
-                const int p = p0 + 32 * j;
+                const int p = p0 + NRG * j;
                 if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
             }
         }
     }
-    red[rgrp * kCombineCols + (lane & 31)] = acc;
+    red[rgrp * kCombineCols + col] = acc;
     __syncthreads();
     float tot = 0.0f;
     if (wave == 0) {       // both halves of the wave compute the same 32 sums, in row-group order
 #pragma unroll
-        for (int rg = 0; rg < 32; ++rg) tot += red[rg * kCombineCols + (lane & 31)];
+        for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
     }
 
     if (RS == 1) {
-        if (tid < 32 && n < a.TA) combine_apply(a, n, uin, tot, nabla);
+        if (tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, tot, nabla);
     } else {
         // publish this split's 64 sums, then take a ticket (guide: agent-scope release before
         // the counter, agent-scope acquire in the last arriver, waits written out by hand)
-        if (tid < 32 && n < a.TA) a.slab[(size_t)rs * a.TA + n] = tot;
+        if (tid < kCombineCols && n < a.TA) a.slab[(size_t)rs * a.TA + n] = tot;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -352,7 +354,7 @@ k_combine(const CombineArgs a, const GenArgs gen)
             last_flag = is_last;
         }
         __syncthreads();
-        if (last_flag && tid < 32 && n < a.TA) {
+        if (last_flag && tid < kCombineCols && n < a.TA) {
             float t2 = 0.0f;
             for (int q = 0; q < RS; ++q)
                 t2 += __hip_atomic_load(&a.slab[(size_t)q * a.TA + n], __ATOMIC_RELAXED,
@@ -584,7 +586,8 @@ hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming 
     const int cols = (a.TA + kCombineCols - 1) / kCombineCols;
     // Row splits meet through an agent-scope ticket (~3 us of fences), so a single split with
     // every row load in flight is preferred for as long as the rows fit 20 registers per lane.
-    int rs = a.row_splits > 0 ? a.row_splits : (a.n_parts + 32 * 20 - 1) / (32 * 20);
+    constexpr int kRowGroups = 16 * (64 / kCombineCols);
+    int rs = a.row_splits > 0 ? a.row_splits : (a.n_parts + kRowGroups * 20 - 1) / (kRowGroups * 20);
     if (rs < 1) rs = 1;
     if (rs > kMaxRowSplits) rs = kMaxRowSplits;
     a.n_cols = cols;
@@ -601,7 +604,7 @@ hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming 
         gen_A = 0;
     }
     const dim3 grid((unsigned)(cols * rs + n_gen));
-    const int rows_per_wave = ((a.n_parts + rs - 1) / rs + 31) / 32;   // per row group
+    const int rows_per_wave = ((a.n_parts + rs - 1) / rs + kRowGroups - 1) / kRowGroups;   // per row group
     if (rows_per_wave <= 8) launch_combine_nr<8>(gen_A, grid, a, g, st, tm);
     else if (rows_per_wave <= 20) launch_combine_nr<20>(gen_A, grid, a, g, st, tm);
     else launch_combine_nr<40>(gen_A, grid, a, g, st, tm);

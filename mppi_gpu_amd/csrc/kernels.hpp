@@ -125,7 +125,7 @@ struct CombineArgs {
 
 constexpr int kRolloutThreads = 256;
 constexpr int kCombineThreads = 1024;
-constexpr int kCombineCols = 32;
+constexpr int kCombineCols = 16;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
 constexpr int kParamFloats = 32;   // LDS floats holding the problem constants in the fused rollout
