@@ -131,6 +131,59 @@ __device__ __forceinline__ float symmetric_strided_sum(float x)
     return x;
 }
 
+// In-place two-register lane swaps (gfx950):
+//   swap16_pair(a, b): a' = {a.r0, b.r0, a.r2, b.r2}, b' = {a.r1, b.r1, a.r3, b.r3}   (16-lane rows)
+//   swap32_pair(a, b): a' = {a.lo32, b.lo32},          b' = {a.hi32, b.hi32}
+// so a' + b' sums each input over a pair of rows (halves) AND sorts the two inputs into
+// different rows (halves): one swap + one add is a reduce-scatter step for two values.
+__device__ __forceinline__ void swap16_pair(float& a, float& b)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32_pair(float& a, float& b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// Weighted-noise sums of one Philox block: x[0..3] are this lane's four weighted normals of the
+// block; the sum of each over the lanes with the same chunk index c (lane % 2^LOGC) is written
+// to dst[0..3] (the block's four floats in the wave's LDS row).  Reduce-scatter: inside a
+// 16-lane row by DPP rotations (decreasing distance: symmetric), across the four rows by the
+// pair swaps above, after which row t of the wave holds the finished sum of x[t]; 2.75
+// instructions per value at C = 16 instead of 7 for four independent butterflies.
+template <int LOGC>
+__device__ __forceinline__ void nreduce_block(float (&x)[4], float* dst, int lane)
+{
+    constexpr int C = 1 << LOGC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (LOGC <= 3) x[i] += dpp<MPPI_ROW_ROR(8)>(x[i]);
+        if constexpr (LOGC <= 2) x[i] += dpp<MPPI_ROW_ROR(4)>(x[i]);
+        if constexpr (LOGC <= 1) x[i] += dpp<MPPI_ROW_ROR(2)>(x[i]);
+        if constexpr (LOGC <= 0) x[i] += dpp<MPPI_ROW_ROR(1)>(x[i]);
+    }
+    if constexpr (LOGC <= 4) {
+        swap16_pair(x[0], x[1]);
+        swap16_pair(x[2], x[3]);
+        float y01 = x[0] + x[1];
+        float y23 = x[2] + x[3];
+        swap32_pair(y01, y23);
+        const float z = y01 + y23;                      // row t of the wave: total of x[t]
+        if ((lane & 15) < C) dst[lane >> 4] = z;
+    } else if constexpr (LOGC == 5) {
+        swap32_pair(x[0], x[1]);
+        swap32_pair(x[2], x[3]);
+        dst[lane >> 5] = x[0] + x[1];                   // half t of the wave: total of x[t]
+        dst[2 + (lane >> 5)] = x[2] + x[3];
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
 // DPP moves used by the chunk scan (all verified on gfx950 by tools/dpp_probe):
 //   row_shr:D      lane i <- lane i-D inside its 16-lane row (0 shifted in)
 //   row_bcast:15   rows 1 and 3 <- lane 15 of the row below     (row_mask 0xA)

@@ -154,10 +154,10 @@ int ensure_geometry(mppi_engine_t* e)
                 return fail(MPPI_EINVAL, "chunks must be a power of two in [%d, 64], got %d", Cmin,
                             C);
         } else {
-            // measured on MI355X (profiles/): lanes that hold <= 7 groups (<= 2 for act_dim 3,
+            // measured on MI355X (profiles/): lanes that hold <= 7 groups (<= 4 for act_dim 3,
             // whose groups are 3 Philox blocks) keep the kernel at >= 4 waves per SIMD; beyond
             // that, more lanes per trajectory only help while the chip is under-filled
-            const int ng_pref = (e->A == 3) ? 2 : 7;
+            const int ng_pref = (e->A == 3) ? 4 : 7;
             C = Cmin;
             while (C < 64 && (NGT + C - 1) / C > ng_pref) C <<= 1;
             while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NGT + 2 * C - 1) / (2 * C) >= 4)

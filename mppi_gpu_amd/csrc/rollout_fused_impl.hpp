@@ -308,19 +308,17 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             if (lane == 0) misc[4 + wave] = sw;
         }
         const float wtN = ((long long)kglob < k_cover) ? wt : 0.0f;
-        // one float4 LDS store per Philox block from the first C lanes
-        float4* wrow = reinterpret_cast<float4*>(wsum + wave * TAp + (c * nq) * 4);
+        float* wrow = wsum + wave * TAp + (c * nq) * 4;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (gi < ng) {
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
                     const int q = gi * BPG + j;
-                    float sv[4];
+                    float xw[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        sv[i] = symmetric_strided_sum<LOGC>(wtN * e[q * 4 + i]);
-                    if (lane < C) wrow[q] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                    for (int i = 0; i < 4; ++i) xw[i] = wtN * e[q * 4 + i];
+                    nreduce_block<LOGC>(xw, wrow + q * 4, lane);
                 }
             }
         }
