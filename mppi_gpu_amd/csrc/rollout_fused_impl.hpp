@@ -116,10 +116,10 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
 
         // ---- pass 1a: draw (or load) the chunk's noise into registers and store it ----------
         float e[NE];
+        // (groups gi >= ng of a template larger than the chunk are never read: every use below
+        //  sits under the same wave-uniform `gi < ng`, so e[] needs no initialisation)
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-#pragma unroll
-            for (int i = 0; i < BPG * 4; ++i) e[gi * BPG * 4 + i] = 0.f;
             if (gi < ng) {
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
