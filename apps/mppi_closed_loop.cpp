@@ -6,7 +6,7 @@
 // the solve must fit 10 ms.
 //
 //   mppi_closed_loop [-c config.yaml] [--dims A] [--samples K] [--horizon T] [--dt 0.1] [--model file.xml]
-//                    [--seconds S] [--traj out.csv] [--lambda L] [--noise SIGMA]
+//                    [--seconds S] [-t|--traj out.csv] [-s|--step-save prefix] [--lambda L] [--noise SIGMA]
 // -c reads a configuration file with the reference's keys (include/mppi_config.hpp); options
 // given after it override single values (the reference's -c/--config, src/main.cu:401-453))
 #include "mppi_config.hpp"
@@ -40,12 +40,52 @@ static void to_csv_traj(const std::string& filename, const std::vector<std::vect
     }
 }
 
+// per-step dump of the reference's save_step mode (src/main.cu:90-156, to_csv2; -s/--step-save),
+// same column order, generalised from the reference's hard-coded 2-D columns to A axes:
+// sample, states (positions, velocities), e, u[d], u_prev[d] (first sample's rows only), c, w
+static void to_csv_step(const std::string& filename, const float* x, const float* u,
+                        const float* u_prev, const float* e, const float* cost, const float* wts,
+                        int sample, int size, int s_dim, int a_dim)
+{
+    std::ofstream out(filename);
+    const char* ax[4] = {"x", "y", "z", "w"};
+    out << "sample";
+    for (int d = 0; d < a_dim; ++d) out << "," << ax[d];
+    for (int d = 0; d < a_dim; ++d) out << "," << ax[d] << "_dot";
+    for (int d = 0; d < a_dim; ++d) out << ",e_" << ax[d];
+    for (int d = 0; d < a_dim; ++d) out << ",u[" << d << "]";
+    for (int d = 0; d < a_dim; ++d) out << ",u_prev[" << d << "]";
+    out << ",c,w\n";
+    for (int i = 0; i < sample; ++i) {
+        for (int j = 0; j < size + 1; ++j) {
+            out << i;
+            for (int d = 0; d < s_dim; ++d) out << "," << x[((size_t)i * (size + 1) + j) * s_dim + d];
+            for (int d = 0; d < a_dim; ++d) {
+                out << ",";
+                if (j < size) out << e[((size_t)i * size + j) * a_dim + d];
+            }
+            for (int d = 0; d < a_dim; ++d) {
+                out << ",";
+                if (i < 1 && j < size) out << u[j * a_dim + d];
+            }
+            for (int d = 0; d < a_dim; ++d) {
+                out << ",";
+                if (i < 1 && j < size) out << u_prev[j * a_dim + d];
+            }
+            // the reference lists cost and weight of sample number (row index) on the first rows
+            const size_t row = (size_t)i * (size + 1) + j;
+            if (row < (size_t)sample) out << "," << cost[row] << "," << wts[row];
+            out << "\n";
+        }
+    }
+}
+
 int main(int argc, char** argv)
 {
     int A = 3, K = 100000, T = 200;
     float dt = 0.1f, lambda = 1.0f, sigma = 0.025f;
     double seconds = 2.0;
-    std::string model, traj;
+    std::string model, traj, step_prefix;
     std::vector<float> cfg_goal, cfg_w, cfg_init;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
@@ -66,7 +106,8 @@ int main(int argc, char** argv)
         else if (k == "--dt") dt = (float)atof(v.c_str());
         else if (k == "--model") model = v;
         else if (k == "--seconds") seconds = atof(v.c_str());
-        else if (k == "--traj") traj = v;
+        else if (k == "--traj" || k == "-t") traj = v;
+        else if (k == "--step-save" || k == "-s") step_prefix = v;
         else if (k == "--lambda") lambda = (float)atof(v.c_str());
         else if (k == "--noise") sigma = (float)atof(v.c_str());
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -110,6 +151,14 @@ int main(int argc, char** argv)
         env.get_x(x.data());
         us.push_back(next_act);
         xs.push_back(x);
+        if (!step_prefix.empty()) {          // reference src/main.cu:355-366 (save_step)
+            std::vector<float> hx((size_t)K * (T + 1) * S), hu((size_t)T * A), he((size_t)K * T * A),
+                hc(K), hw(K);
+            float beta = 0, nabla = 0;
+            model_ctl->get_inf(hx.data(), hu.data(), he.data(), hc.data(), &beta, &nabla, hw.data());
+            to_csv_step(step_prefix + std::to_string(t), hx.data(), hu.data(), u_prev.data(),
+                        he.data(), hc.data(), hw.data(), K, T, S, A);
+        }
         model_ctl->set_x(x.data());
         ++t;
     }

@@ -95,3 +95,23 @@ def test_closed_loop_config5_meets_100hz_budget(gpu, tmp_path):
     assert "Average controller execution time" in out.stdout
     rows = traj.read_text().strip().splitlines()
     assert rows[0].startswith("x,y,z,vx,vy,vz,ux,uy,uz,size_x,size_u") and len(rows) == steps + 2, len(rows)
+
+
+@pytest.mark.gpu
+def test_step_save_dump_matches_get_inf_columns(gpu, tmp_path):
+    """-s/--step-save: the per-step dump (reference to_csv2 column order, generalised to A axes)
+    holds what get_inf returns: weights sum to 1, trajectories start at the plant state."""
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    pref = str(tmp_path / "step")
+    out = subprocess.run([exe, "--dims", "2", "--samples", "40", "--horizon", "12", "--seconds", "0.05",
+                          "-s", pref], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = open(pref + "0").read().strip().splitlines()
+    assert rows[0] == "sample,x,y,x_dot,y_dot,e_x,e_y,u[0],u[1],u_prev[0],u_prev[1],c,w"
+    assert len(rows) == 1 + 40 * 13
+    body = [r.split(",") for r in rows[1:]]
+    wsum = sum(float(r[12]) for r in body[:40])
+    assert abs(wsum - 1.0) < 1e-4
+    first = body[0]
+    assert [float(v) for v in first[1:5]] == [0.0, 0.0, 0.0, 0.0]      # row t=0 of sample 0 is x0
+    assert first[5] != "" and first[7] != "" and body[13][7] == ""      # u only on sample 0 rows
