@@ -115,7 +115,8 @@ int mppi_set_pipeline(mppi_engine* e, int on);
 
 /* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */
 
-/* Enqueue one full solve on `stream` (a hipStream_t, NULL = the engine's own stream) and
+/* Enqueue one full solve on `stream` (a hipStream_t; NULL = the engine's own non-blocking stream --
+ * note that the legacy default stream also has the handle NULL, so pass a created stream) and
  * return without waiting.  The action lands in a pinned host word readable after
  * mppi_sync_act.  Solves on one engine are ordered on the stream. */
 int mppi_solve_async(mppi_engine* e, void* stream);

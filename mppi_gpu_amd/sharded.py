@@ -55,8 +55,21 @@ class ShardedPointMassModel:
         self._partial = tensor_factory(self.L)
         self._gathered = tensor_factory(self.L * self.world)
         self._stream = None
+        self._tstream = None
+        self._host_staging = None
         if self._partial.is_cuda:
-            self._stream = torch.cuda.current_stream().cuda_stream
+            # A dedicated torch stream carries the engine's kernels AND the collective, in order.
+            # (torch's default stream has the raw handle 0, which the C ABI reads as "use the
+            # engine's own stream": kernels and all-gather would then run unordered.)
+            self._tstream = torch.cuda.Stream()
+            self._stream = self._tstream.cuda_stream
+            assert self._stream != 0
+            if dist.get_backend(group) != "nccl":
+                # rehearsal transport (gloo): gather through pinned host tensors.  RCCL is the
+                # production transport; this path exists so that the multi-process device code
+                # can be exercised with several ranks on ONE GPU, which RCCL does not allow.
+                self._host_staging = (torch.zeros(self.L, dtype=torch.float32).pin_memory(),
+                                      torch.zeros(self.L * self.world, dtype=torch.float32).pin_memory())
 
     def memcpy_set_data(self, x, u, goal, w):
         self.engine.memcpy_set_data(x, u, goal, w)
@@ -66,18 +79,31 @@ class ShardedPointMassModel:
 
     def solve_async(self):
         """Enqueue one sharded solve: local rollout + reduction, all-gather, combine."""
-        self.engine.solve_local_async(self._partial.data_ptr(), self._stream)
-        self._dist.all_gather_into_tensor(self._gathered, self._partial, group=self._group)
-        self.engine.solve_finish_async(self._gathered.data_ptr(), self.world, self._stream)
+        if self._tstream is None:                    # CPU rehearsal (test doubles)
+            self.engine.solve_local_async(self._partial.data_ptr(), None)
+            self._dist.all_gather_into_tensor(self._gathered, self._partial, group=self._group)
+            self.engine.solve_finish_async(self._gathered.data_ptr(), self.world, None)
+            return
+        import torch
+        with torch.cuda.stream(self._tstream):
+            self.engine.solve_local_async(self._partial.data_ptr(), self._stream)
+            if self._host_staging is None:
+                self._dist.all_gather_into_tensor(self._gathered, self._partial, group=self._group)
+            else:
+                hp, hg = self._host_staging
+                hp.copy_(self._partial, non_blocking=True)       # stream-ordered D2H
+                self._tstream.synchronize()
+                self._dist.all_gather_into_tensor(hg, hp, group=self._group)
+                self._gathered.copy_(hg, non_blocking=True)
+            self.engine.solve_finish_async(self._gathered.data_ptr(), self.world, self._stream)
 
     def get_act(self):
         self.solve_async()
         return self.sync_act()
 
     def sync_act(self):
-        if self._stream is not None:
-            import torch
-            torch.cuda.current_stream().synchronize()
+        if self._tstream is not None:
+            self._tstream.synchronize()
         return self.engine.sync_act()
 
     def get_u(self):

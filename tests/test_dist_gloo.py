@@ -121,3 +121,45 @@ def test_two_rank_gloo_sharded_solve_equals_single_process_oracle():
         assert np.abs(acts0[it] - ref["next_act"]).max() <= 1e-5 * scale, it
         U = ref["U"]
     assert np.abs(U0 - U).max() <= 1e-5 * max(float(np.abs(U).max()), 0.025)
+
+
+def _gpu_worker(rank, world, port, K, A, T, seed, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch as th
+    th.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mppi_gpu_amd.sharded import ShardedPointMassModel
+    case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
+    m = ShardedPointMassModel(K, T, float(case["dt"]), 2 * A, A)
+    m.engine.set_seed(seed)
+    m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
+    acts = [m.get_act().copy() for _ in range(3)]
+    ret[rank] = (np.stack(acts), m.get_u().copy())
+    m.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_sharing_one_gpu_equal_single_engine(gpu):
+    """The real multi-process device path: two ranks (two processes, both on cuda:0, gloo as the
+    transport because RCCL wants one GPU per rank) run the sharded engine kernels
+    (solve_local / finish) and must reproduce the single-engine solve of the whole batch."""
+    from mppi_gpu_amd import PointMassModel
+    K, A, T, seed, world = 5001, 2, 200, 23, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_gpu_worker, args=(world, port, K, A, T, seed, ret), nprocs=world, join=True)
+    acts0, U0 = ret[0]
+    acts1, U1 = ret[1]
+    assert np.array_equal(acts0, acts1) and np.array_equal(U0, U1), "ranks must agree bitwise"
+    case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
+    with PointMassModel(K, T, float(case["dt"]), 2 * A, A) as m:
+        m.set_seed(seed)
+        m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
+        for it in range(3):
+            a = m.get_act()
+            scale = max(float(np.abs(m.get_u()).max()), 0.025)
+            assert np.abs(a - acts0[it]).max() <= 2e-6 * scale, it
+        assert np.abs(m.get_u() - U0).max() <= 5e-6 * scale
