@@ -6,7 +6,8 @@ update + shift) on synthetic point-mass data, BASELINE.json's metric.
 
 A "step" is one MPPI solve over one batch of rollouts.  Default workload = BASELINE configs[1]:
 point_mass2d, K = 1e4 rollouts, T = 200 steps, per GPU (weak scaling: with N GPUs the global
-batch is N*K, sharded by sample; the only exchange is one all-gather of T*A+2 floats per solve).
+batch is N*K, sharded by sample; the only exchange is T*A+2 floats per rank and solve, written by
+the combine kernel straight into the peers' inboxes over xGMI, or an RCCL all-gather: --transport).
 Inputs are resident on the device before the timed region; the timed region is bracketed by a
 barrier + torch.cuda.synchronize() on both sides; value = N*K*steps / max-over-ranks time.
 
@@ -80,6 +81,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="draw each solve's noise one solve ahead inside the combine launch "
                          "(measured slower; default is in-place sampling)")
+    ap.add_argument("--transport", choices=("auto", "direct", "collective"), default="auto",
+                    help="rank-partial exchange of the sharded solve: direct peer stores, RCCL "
+                         "all-gather, or auto (direct if it validates against the collective)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (local solve, RCCL all-gather, finish) even "
                          "with one rank: rehearsal of the N > 1 path on a one-GPU box")
@@ -119,12 +123,13 @@ def main():
         sharded = None
     else:
         from mppi_gpu_amd.sharded import ShardedPointMassModel
-        sharded = ShardedPointMassModel(N * K, T, float(c["dt"]), 2 * A, A)
+        sharded = ShardedPointMassModel(N * K, T, float(c["dt"]), 2 * A, A,
+                                        transport=args.transport)
         m = sharded.engine          # this rank's shard: samples [rank*K, (rank+1)*K)
     m.set_pipeline(args.pipeline)
     m.set_tuning(chunks=args.chunks, strict=args.strict, max_blocks=args.max_blocks)
     m.set_seed(0)
-    m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+    (sharded or m).memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
     geo = m.geometry()
     if args.inject:
         m.set_noise(np.zeros((K, T, A), np.float32))
@@ -186,6 +191,9 @@ def main():
             "data": "synthetic" if not args.inject else "INVALID: injected zero noise (analysis run)",
             "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
                        "global_rollouts": N * K, "sharding": f"samples x{N}",
+                       "exchange": None if sharded is None else
+                       {"direct": "combine kernel -> peer inboxes over xGMI (hipIpc), no collective",
+                        "collective": "RCCL all-gather of T*A+2 floats"}[sharded.transport],
                        "geometry": geo, "rollout_steps_per_s": value * T},
             "roofline": roof,
         }

@@ -135,6 +135,26 @@ int mppi_partial_len(const mppi_engine* e);
 int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream);
 int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream);
 
+/* Direct peer exchange: the sharded solve WITHOUT a collective library on the data path.
+ * Every rank owns an inbox in uncached device memory; mppi_xchg_open allocates it and returns its
+ * hipIpc handle (mppi_xchg_handle_bytes() bytes) and/or its raw device pointer. The caller
+ * distributes the handles out of band (any transport: torch.distributed, MPI, a file) and hands
+ * mppi_xchg_connect the `world` handles in rank order; ranks living in the SAME process pass
+ * their raw pointers in same_process[rank] instead (hipIpc cannot open a handle in the process
+ * that made it); either argument may be NULL.  After that one call per solve,
+ * mppi_solve_exchange_async, enqueues the rollout and ONE combine launch that stores this rank's
+ * [beta_g, S_g, N_g[T*A]] into all inboxes as 8-byte {value, sequence tag} words over xGMI,
+ * polls its own inbox for the other ranks' words and applies the update -- bit-identical to
+ * mppi_solve_local_async + all-gather + mppi_solve_finish_async.  All ranks must make the same
+ * sequence of exchange calls; a rank that waits longer than the time-out (default 5 s) gives up,
+ * and the next mppi_sync_act / mppi_get_act returns MPPI_ESTATE.  world <= 64. */
+int mppi_xchg_handle_bytes(void);
+int mppi_xchg_open(mppi_engine* e, int rank, int world, void* handle_out, void** inbox_out);
+int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_process);
+int mppi_xchg_set_timeout(mppi_engine* e, double seconds);
+int mppi_solve_exchange_async(mppi_engine* e, void* stream);
+int mppi_xchg_close(mppi_engine* e);
+
 /* ---- measurement ------------------------------------------------------------------- */
 
 /* every > 0: each `every`-th solve records HIP events around its kernels on the launch stream

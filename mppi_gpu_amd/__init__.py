@@ -190,6 +190,33 @@ class PointMassModel:
         check(self._lib.mppi_solve_finish_async(self._h, C.c_void_p(d_gathered_ptr), int(n_parts),
                                                 C.c_void_p(stream or 0)))
 
+    # -- direct peer exchange (include/mppi_gpu_amd.h "Direct peer exchange") -----------------
+    def xchg_open(self, rank, world):
+        """Allocate this rank's inbox; returns (ipc_handle_bytes, raw_device_pointer)."""
+        n = self._lib.mppi_xchg_handle_bytes()
+        buf = C.create_string_buffer(n)
+        ptr = C.c_void_p()
+        check(self._lib.mppi_xchg_open(self._h, int(rank), int(world), buf, C.byref(ptr)))
+        return buf.raw, ptr.value
+
+    def xchg_connect(self, handles=None, same_process=None):
+        """handles: the world ipc handles concatenated in rank order (bytes) or None;
+        same_process: list of raw inbox pointers (None/0 where the handle is to be used)."""
+        hb = C.create_string_buffer(handles, len(handles)) if handles is not None else None
+        arr = None
+        if same_process is not None:
+            arr = (C.c_void_p * len(same_process))(*[C.c_void_p(p or 0) for p in same_process])
+        check(self._lib.mppi_xchg_connect(self._h, hb, arr))
+
+    def xchg_set_timeout(self, seconds):
+        check(self._lib.mppi_xchg_set_timeout(self._h, float(seconds)))
+
+    def solve_exchange_async(self, stream=None):
+        check(self._lib.mppi_solve_exchange_async(self._h, C.c_void_p(stream or 0)))
+
+    def xchg_close(self):
+        check(self._lib.mppi_xchg_close(self._h))
+
     # -- measurement ------------------------------------------------------------------------
     def set_profiling(self, every):
         """every > 0: record HIP events around the kernels of each `every`-th solve."""

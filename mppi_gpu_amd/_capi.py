@@ -41,6 +41,12 @@ SIGNATURES = {
     "mppi_partial_len": (C.c_int, [engine_p]),
     "mppi_solve_local_async": (C.c_int, [engine_p, C.c_void_p, C.c_void_p]),
     "mppi_solve_finish_async": (C.c_int, [engine_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mppi_xchg_handle_bytes": (C.c_int, []),
+    "mppi_xchg_open": (C.c_int, [engine_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_xchg_connect": (C.c_int, [engine_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mppi_xchg_set_timeout": (C.c_int, [engine_p, C.c_double]),
+    "mppi_solve_exchange_async": (C.c_int, [engine_p, C.c_void_p]),
+    "mppi_xchg_close": (C.c_int, [engine_p]),
     "mppi_set_profiling": (C.c_int, [engine_p, C.c_int]),
     "mppi_kernel_ms": (C.c_int, [engine_p, C.c_int, c_double_p, c_int_p]),
     "mppi_get_geometry": (C.c_int, [engine_p, c_int_p]),

@@ -109,6 +109,18 @@ struct mppi_engine {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the most recent enqueue
 
+    // direct peer exchange (mppi_xchg_*)
+    int xg_rank = -1, xg_world = 0, xg_W = 0;
+    bool xg_connected = false;
+    unsigned long long* xg_inbox = nullptr;            // this rank's inbox (uncached device memory)
+    std::vector<void*> xg_opened;                      // hipIpcOpenMemHandle mappings to close
+    unsigned long long** d_xg_peers = nullptr;         // device table of the G inbox bases
+    unsigned long long xg_seq = 0;                     // exchanges done; never reset
+    double xg_timeout_s = 5.0;
+    int* d_xg_err = nullptr;
+    int* h_xg_err = nullptr;                           // pinned + mapped
+    int* h_xg_err_dev = nullptr;
+
     // profiling
     int prof = 0;                   // 0 = off, n = record every n-th solve
     bool prof_now = false;
@@ -374,7 +386,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
 
 int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const float* s,
                     const float* N, long long ms, long long ss, long long Ns, int n_parts,
-                    bool final_mode, float* partial_out, bool prefetch_noise = false)
+                    int mode, float* partial_out, bool prefetch_noise = false)
 {
     if (n_parts < 1 || n_parts > mppi::kMaxParts)
         return fail(MPPI_EINVAL, "n_parts %d out of range", n_parts);
@@ -393,7 +405,20 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     ca.slab = e->d_slab;
     ca.tickets = e->d_tickets;
     ca.solve_idx = e->solve_idx;
-    ca.final_mode = final_mode ? 1 : 0;
+    ca.final_mode = mode;
+    memset(&ca.x, 0, sizeof ca.x);
+    if (mode == 2) {
+        if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
+        ca.x.peers = e->d_xg_peers;
+        ca.x.G = e->xg_world;
+        ca.x.rank = e->xg_rank;
+        ca.x.W = e->xg_W;
+        ca.x.parity = (int)(e->xg_seq & 1ull);
+        ca.x.tag = (unsigned int)(e->xg_seq % 0xFFFFFFFFull) + 1u;
+        ca.x.timeout_ticks = (unsigned long long)(e->xg_timeout_s * 1e8);   // 100 MHz clock
+        ca.x.err_dev = e->d_xg_err;
+        ca.x.err_host = e->h_xg_err_dev;
+    }
     {
         const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
         ca.row_splits = env ? atoi(env) : 0;
@@ -507,6 +532,10 @@ void mppi_destroy(mppi_engine* e)
 {
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)mppi_xchg_close(e);
+    (void)hipFree(e->d_xg_peers);
+    (void)hipFree(e->d_xg_err);
+    if (e->h_xg_err) (void)hipHostFree(e->h_xg_err);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_state);
     (void)hipFree(e->d_U);
@@ -569,7 +598,7 @@ int mppi_solve_async(mppi_engine* e, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, true, nullptr,
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr,
                          true);
     if (rc) return rc;
     e->solve_idx += 1;
@@ -585,6 +614,12 @@ int mppi_sync_act(mppi_engine* e, float* next_act)
     HIPCHK(hipStreamSynchronize(e->stream));
     if (next_act)
         for (int i = 0; i < e->A; ++i) next_act[i] = e->h_act[i];
+    if (e->h_xg_err && *e->h_xg_err) {
+        *e->h_xg_err = 0;
+        (void)hipMemset(e->d_xg_err, 0, sizeof(int));
+        return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
+                    "solve %llu", e->xg_timeout_s, e->solve_idx);
+    }
     return MPPI_OK;
 }
 
@@ -737,7 +772,7 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, false, d_partial,
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial,
                          true);
     return rc;
 }
@@ -745,12 +780,128 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
 int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream)
 {
     if (!e || !d_gathered) return fail(MPPI_EINVAL, "null argument");
+    if (n_parts < 1 || n_parts > mppi::kMaxRanks)
+        return fail(MPPI_EINVAL, "n_parts %d out of range (1..%d)", n_parts, mppi::kMaxRanks);
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    const long long stride = e->TA + 2;
     e->prof_now = false;   // kernel_ms() reports the rollout and the rank-local combine only
-    int rc = enqueue_combine(e, st, d_gathered, d_gathered + 1, d_gathered + 2, stride, stride,
-                             stride, n_parts, true, nullptr);
+    mppi::CombineArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.dev = e->d_state;
+    ca.TA = e->TA;
+    ca.A = e->A;
+    ca.inv_lambda = 1 / e->lambda;
+    ca.U = e->d_U;
+    ca.act_dev = e->d_act;
+    ca.act_host = e->h_act_dev;
+    ca.solve_idx = e->solve_idx;
+    ca.final_mode = 1;
+    HIPCHK(mppi::launch_finish_gathered(ca, d_gathered, n_parts, st));
+    e->last_stream = st;
+    e->solve_idx += 1;
+    e->have_solve = true;
+    return MPPI_OK;
+}
+
+// ---- direct peer exchange ------------------------------------------------------------------
+int mppi_xchg_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+int mppi_xchg_open(mppi_engine* e, int rank, int world, void* handle_out, void** inbox_out)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (world < 1 || world > mppi::kMaxRanks || rank < 0 || rank >= world)
+        return fail(MPPI_EINVAL, "rank %d / world %d out of range (world <= %d)", rank, world,
+                    mppi::kMaxRanks);
+    if (e->xg_inbox) return fail(MPPI_ESTATE, "exchange already open");
+    e->xg_rank = rank;
+    e->xg_world = world;
+    e->xg_W = ((e->TA + 2 + 15) / 16) * 16;
+    const size_t bytes = 2ull * world * e->xg_W * sizeof(unsigned long long);
+    // uncached device memory: peer stores land in HBM and local polls read HBM (what RCCL uses
+    // for its flag/LL buffers); fine-grained as the fallback
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+    }
+    e->xg_inbox = (unsigned long long*)p;
+    HIPCHK(hipMemset(p, 0, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    if (!e->d_xg_peers) HIPCHK(hipMalloc(&e->d_xg_peers, mppi::kMaxRanks * sizeof(void*)));
+    if (!e->d_xg_err) {
+        HIPCHK(hipMalloc(&e->d_xg_err, sizeof(int)));
+        HIPCHK(hipMemset(e->d_xg_err, 0, sizeof(int)));
+        HIPCHK(hipHostMalloc(&e->h_xg_err, sizeof(int), hipHostMallocMapped));
+        *e->h_xg_err = 0;
+        HIPCHK(hipHostGetDevicePointer((void**)&e->h_xg_err_dev, e->h_xg_err, 0));
+    }
+    if (handle_out) {
+        hipIpcMemHandle_t h;
+        HIPCHK(hipIpcGetMemHandle(&h, p));
+        memcpy(handle_out, &h, sizeof h);
+    }
+    if (inbox_out) *inbox_out = p;
+    return MPPI_OK;
+}
+
+int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_process)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (!e->xg_inbox) return fail(MPPI_ESTATE, "mppi_xchg_open first");
+    if (e->xg_connected) return fail(MPPI_ESTATE, "exchange already connected");
+    if (!handles && !same_process) return fail(MPPI_EINVAL, "no handles and no pointers");
+    std::vector<unsigned long long*> tab(mppi::kMaxRanks, nullptr);
+    for (int g = 0; g < e->xg_world; ++g) {
+        if (g == e->xg_rank) {
+            tab[g] = e->xg_inbox;
+        } else if (same_process && same_process[g]) {
+            tab[g] = (unsigned long long*)same_process[g];
+        } else if (handles) {
+            hipIpcMemHandle_t h;
+            memcpy(&h, (const char*)handles + (size_t)g * sizeof h, sizeof h);
+            void* p = nullptr;
+            HIPCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            e->xg_opened.push_back(p);
+            tab[g] = (unsigned long long*)p;
+        } else {
+            return fail(MPPI_EINVAL, "no inbox for rank %d", g);
+        }
+    }
+    HIPCHK(hipMemcpy(e->d_xg_peers, tab.data(), mppi::kMaxRanks * sizeof(void*),
+                     hipMemcpyHostToDevice));
+    e->xg_connected = true;
+    return MPPI_OK;
+}
+
+int mppi_xchg_set_timeout(mppi_engine* e, double seconds)
+{
+    if (!e || !(seconds > 0.0) || seconds > 60.0) return fail(MPPI_EINVAL, "timeout in (0, 60] s");
+    e->xg_timeout_s = seconds;
+    return MPPI_OK;
+}
+
+int mppi_xchg_close(mppi_engine* e)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (e->last_stream) (void)hipStreamSynchronize(e->last_stream);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->xg_opened) (void)hipIpcCloseMemHandle(p);
+    e->xg_opened.clear();
+    if (e->xg_inbox) (void)hipFree(e->xg_inbox);
+    e->xg_inbox = nullptr;
+    e->xg_connected = false;
+    return MPPI_OK;
+}
+
+int mppi_solve_exchange_async(mppi_engine* e, void* stream)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    int rc = enqueue_rollout(e, st);
     if (rc) return rc;
+    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr, true);
+    if (rc) return rc;
+    e->xg_seq += 1;
     e->solve_idx += 1;
     e->have_solve = true;
     return MPPI_OK;

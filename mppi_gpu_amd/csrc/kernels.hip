@@ -205,6 +205,78 @@ k_generate(const GenArgs g)
 // arrival order) and applies the update.  The ticket is zero at creation and reset by the
 // last arriver.
 // ------------------------------------------------------------------------------------------
+// ---- rank-partial exchange words (XchgArgs) -------------------------------------------------
+__device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigned int tag)
+{
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Poll inbox word p1 (and p2 when non-null, both loads in flight together) until they carry
+// `tag`; bounded by the exchange time-out so that every wave reaches its exit whatever the
+// peers do.
+__device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const unsigned long long* p2,
+                                         unsigned int tag, unsigned long long limit, float& v1,
+                                         float& v2, int& timed_out)
+{
+    const unsigned long long t0 = wall_clock64();
+    bool ok1 = (p1 == nullptr), ok2 = (p2 == nullptr);
+    v1 = 0.0f;
+    v2 = 0.0f;
+    for (;;) {
+        unsigned long long w1 = 0, w2 = 0;
+        if (!ok1) w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok2) w2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok1 && (unsigned int)(w1 >> 32) == tag) {
+            v1 = __uint_as_float((unsigned int)w1);
+            ok1 = true;
+        }
+        if (!ok2 && (unsigned int)(w2 >> 32) == tag) {
+            v2 = __uint_as_float((unsigned int)w2);
+            ok2 = true;
+        }
+        if (ok1 && ok2) return;
+        if (wall_clock64() - t0 > limit) {
+            timed_out = 1;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// Final combine of G rank partials held in LDS (xm[g], xs[g], xv[g][col]), rank order, one
+// thread per column; shared by the direct exchange and by the gathered (RCCL) path.
+__device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int tid, int G,
+                                               const float* xm, const float* xs, const float* xv,
+                                               float uin)
+{
+    if (tid >= kCombineCols) return;
+    const int n = cb * kCombineCols + tid;
+    float beta = xm[0];
+    for (int g = 1; g < G; ++g) beta = fminf(beta, xm[g]);
+    float nabla = 0.0f, tot = 0.0f;
+    for (int g = 0; g < G; ++g) {
+        const float r = (xm[g] < INFINITY) ? expf(-a.inv_lambda * (xm[g] - beta)) : 0.0f;
+        nabla = fmaf(r, xs[g], nabla);
+        tot = fmaf(r, xv[g * kCombineCols + tid], tot);
+    }
+    if (n < a.TA) {
+        float* Uout = a.U + ((a.solve_idx + 1ull) & 1ull) * a.TA;
+        const float unew = uin + tot / nabla;
+        if (n < a.A) {
+            a.act_dev[n] = unew;
+            if (a.act_host) a.act_host[n] = unew;
+        } else {
+            Uout[n - a.A] = unew;
+        }
+        if (n >= a.TA - a.A) Uout[n] = unew;   // last step repeated
+    }
+    if (cb == 0 && tid == 0) {
+        a.dev->beta = beta;
+        a.dev->nabla = nabla;
+    }
+}
+
 __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float uin, float tot,
                                               float nabla)
 {
@@ -277,7 +349,7 @@ k_combine(const CombineArgs a, const GenArgs gen)
         v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
     }
     float uin = 0.0f;
-    if (a.final_mode && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
+    if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
 
     float mloc = mreg[0];
 #pragma unroll
@@ -332,9 +404,11 @@ k_combine(const CombineArgs a, const GenArgs gen)
         for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
     }
 
-    if (RS == 1) {
-        if (tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, tot, nabla);
-    } else {
+    // `mine`: this rank's finished sums for the block's 16 columns (threads 0..15 of the block
+    // that applies them); apply_blk is block-uniform
+    float mine = tot;
+    bool apply_blk = true;
+    if (RS > 1) {
         // publish this split's 64 sums, then take a ticket (guide: agent-scope release before
         // the counter, agent-scope acquire in the last arriver, waits written out by hand)
         if (tid < kCombineCols && n < a.TA) a.slab[(size_t)rs * a.TA + n] = tot;
@@ -354,23 +428,93 @@ k_combine(const CombineArgs a, const GenArgs gen)
             last_flag = is_last;
         }
         __syncthreads();
-        if (last_flag && tid < kCombineCols && n < a.TA) {
+        apply_blk = last_flag != 0;
+        if (apply_blk && tid < kCombineCols && n < a.TA) {
             float t2 = 0.0f;
             for (int q = 0; q < RS; ++q)
                 t2 += __hip_atomic_load(&a.slab[(size_t)q * a.TA + n], __ATOMIC_RELAXED,
                                         __HIP_MEMORY_SCOPE_AGENT);
-            combine_apply(a, n, uin, t2, nabla);
+            mine = t2;
         }
     }
-    if (cb == 0 && rs == 0 && tid == 0) {
-        if (a.final_mode) {
-            a.dev->beta = beta;
-            a.dev->nabla = nabla;
-        } else {
-            a.partial_out[0] = beta;
-            a.partial_out[1] = nabla;
+    if (a.final_mode != 2) {
+        if (apply_blk && tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, mine, nabla);
+        if (cb == 0 && rs == 0 && tid == 0) {
+            if (a.final_mode) {
+                a.dev->beta = beta;
+                a.dev->nabla = nabla;
+            } else {
+                a.partial_out[0] = beta;
+                a.partial_out[1] = nabla;
+            }
+        }
+        return;
+    }
+    if (!apply_blk) return;
+
+    // ---- direct exchange: send this rank's partial to every inbox, collect all G, finish ----
+    const XchgArgs& x = a.x;
+    float* xv = r_lds;                                   // [G][16]   (r_lds is free by now)
+    float* xm = r_lds + kMaxRanks * kCombineCols;        // [G]
+    float* xs = xm + kMaxRanks;                          // [G]
+    float* mine_lds = xs + kMaxRanks;                    // [16]
+    __syncthreads();
+    if (tid < kCombineCols) mine_lds[tid] = (n < a.TA) ? mine : 0.0f;
+    __syncthreads();
+    const int g = tid / kCombineCols;                    // peer this thread talks to
+    const int c = tid & (kCombineCols - 1);
+    const int nn = cb * kCombineCols + c;
+    const size_t slot_w = (size_t)x.W;
+    if (g < x.G) {
+        unsigned long long* dst = x.peers[g] + ((size_t)x.parity * x.G + x.rank) * slot_w;
+        if (nn < a.TA) ll_store(dst + 2 + nn, mine_lds[c], x.tag);
+        if (cb == 0 && c == 0) {
+            ll_store(dst + 0, beta, x.tag);
+            ll_store(dst + 1, nabla, x.tag);
         }
     }
+    int timed_out = 0;
+    if (g < x.G) {
+        const unsigned long long* src = x.peers[x.rank] + ((size_t)x.parity * x.G + g) * slot_w;
+        float v1, v2;   // column word of rank g; columns 0 / 1 also fetch beta_g / S_g
+        ll_poll2((nn < a.TA) ? src + 2 + nn : nullptr, (c < 2) ? src + c : nullptr, x.tag,
+                 x.timeout_ticks, v1, v2, timed_out);
+        xv[g * kCombineCols + c] = v1;
+        if (c == 0) xm[g] = v2;
+        if (c == 1) xs[g] = v2;
+    }
+    if (timed_out) {
+        *x.err_dev = 1;
+        if (x.err_host) *x.err_host = 1;
+    }
+    __syncthreads();
+    finish_columns(a, cb, tid, x.G, xm, xs, xv, uin);
+}
+
+// Final combine of G gathered rank partials (the collective-library transport): one block per 16
+// columns, thread (g, col) loads one value, then the same finish as the direct exchange.
+__global__ void __launch_bounds__(kCombineThreads)
+k_finish_gathered(const CombineArgs a, const float* __restrict__ gathered, int G)
+{
+    __shared__ float xv[kMaxRanks * kCombineCols];
+    __shared__ float xm[kMaxRanks];
+    __shared__ float xs[kMaxRanks];
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x;
+    const int g = tid / kCombineCols;
+    const int c = tid & (kCombineCols - 1);
+    const int nn = cb * kCombineCols + c;
+    const size_t stride = (size_t)a.TA + 2;
+    float uin = 0.0f;
+    if (tid < kCombineCols && nn < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + nn];
+    if (g < G) {
+        const float* src = gathered + (size_t)g * stride;
+        xv[g * kCombineCols + c] = (nn < a.TA) ? src[2 + nn] : 0.0f;
+        if (c == 0) xm[g] = src[0];
+        if (c == 1) xs[g] = src[1];
+    }
+    __syncthreads();
+    finish_columns(a, cb, tid, G, xm, xs, xv, uin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -577,6 +721,15 @@ static void launch_combine_nr(int gen_A, const dim3& grid, const CombineArgs& a,
         case 4: MPPI_LAUNCH((k_combine<NR, 4>), grid, block, 0, st, tm, a, g); break;
         default: MPPI_LAUNCH((k_combine<NR, 0>), grid, block, 0, st, tm, a, g); break;
     }
+}
+
+hipError_t launch_finish_gathered(const CombineArgs& a, const float* gathered, int G,
+                                  hipStream_t st, LaunchTiming tm)
+{
+    if (G < 1 || G > kMaxRanks) return hipErrorInvalidValue;
+    const dim3 grid((a.TA + kCombineCols - 1) / kCombineCols), block(kCombineThreads);
+    MPPI_LAUNCH(k_finish_gathered, grid, block, 0, st, tm, a, gathered, G);
+    return hipGetLastError();
 }
 
 hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming tm,

@@ -99,6 +99,23 @@ inline RolloutHot make_hot(const RolloutArgs& a)
     return h;
 }
 
+// Direct exchange of the rank partials (final_mode 2): every rank owns an INBOX in uncached
+// device memory, mapped into every other rank's process (hipIpc over xGMI); the rank-local
+// combine stores its partial straight into all G inboxes as 8-byte words {float bits, tag} and
+// then polls its own inbox until the G words it needs carry this exchange's tag -- no fence, no
+// flag, no collective library on the data path (a 64-bit store is single-copy atomic).
+//   inbox word (parity, src, i) at  peers[g] + (parity*G + src)*W + i
+//   i = 0: beta_src, 1: S_src, 2+n: N_src[n];  tag = exchange sequence number + 1 (never 0)
+struct XchgArgs {
+    unsigned long long* const* peers;   // [G] device table of inbox bases, rank order
+    int G, rank, W;
+    int parity;
+    unsigned int tag;
+    unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz) before giving up
+    int* err_dev;                       // set to 1 on time-out (device + pinned host copy)
+    int* err_host;
+};
+
 struct CombineArgs {
     DevState* dev;
     const float* m;        // [n_parts] (stride m_stride floats)
@@ -118,7 +135,8 @@ struct CombineArgs {
     float* slab;           // [kMaxRowSplits][TA] row-split sums (RS > 1)
     unsigned int* tickets; // [ceil(TA/64)] arrival counters, zero between launches
     unsigned long long solve_idx;
-    int final_mode;
+    int final_mode;        // 0 partial -> partial_out, 1 final, 2 partial -> peer exchange -> final
+    XchgArgs x;            // final_mode 2 only
     int row_splits;        // 0 = auto
     int n_cols, RS;        // filled by the launcher: column blocks and row splits of the grid
 };
@@ -128,6 +146,7 @@ constexpr int kCombineThreads = 1024;
 constexpr int kCombineCols = 16;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
+constexpr int kMaxRanks = kCombineThreads / kCombineCols;   // one combine thread per (rank, column)
 constexpr int kParamFloats = 32;   // LDS floats holding the problem constants in the fused rollout
 
 // Group geometry by action dimension and the instantiated register-resident chunk lengths
@@ -168,6 +187,11 @@ hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs
 // (act_dim gen_A) -- the next solve's noise, generated underneath this solve's combine.
 hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming(),
                           const GenArgs* gen = nullptr, int gen_A = 0);
+
+// Final combine of G gathered rank partials ([G][TA+2] floats: beta_g, S_g, N_g[TA]) in rank
+// order -- the same arithmetic the direct exchange applies, so both transports give equal bits.
+hipError_t launch_finish_gathered(const CombineArgs& a, const float* gathered, int G,
+                                  hipStream_t st, LaunchTiming tm = LaunchTiming());
 
 // debug / data-movement kernels (off the timed path)
 hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T, int C,

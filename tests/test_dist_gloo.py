@@ -123,7 +123,7 @@ def test_two_rank_gloo_sharded_solve_equals_single_process_oracle():
     assert np.abs(U0 - U).max() <= 1e-5 * max(float(np.abs(U).max()), 0.025)
 
 
-def _gpu_worker(rank, world, port, K, A, T, seed, ret):
+def _gpu_worker(rank, world, port, K, A, T, seed, transport, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch as th
@@ -131,13 +131,29 @@ def _gpu_worker(rank, world, port, K, A, T, seed, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mppi_gpu_amd.sharded import ShardedPointMassModel
     case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
-    m = ShardedPointMassModel(K, T, float(case["dt"]), 2 * A, A)
+    m = ShardedPointMassModel(K, T, float(case["dt"]), 2 * A, A, transport=transport)
     m.engine.set_seed(seed)
     m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
     acts = [m.get_act().copy() for _ in range(3)]
-    ret[rank] = (np.stack(acts), m.get_u().copy())
+    m.set_x(case["x0"] * 0.5)                      # a state update between exchanges
+    acts.append(m.get_act().copy())
+    ret[rank] = (np.stack(acts), m.get_u().copy(), m.transport)
     m.close()
     dist.destroy_process_group()
+
+
+def _run_gpu_ranks(world, K, A, T, seed, transport, port_base):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = port_base + (os.getpid() % 2000)
+    mp.spawn(_gpu_worker, args=(world, port, K, A, T, seed, transport, ret), nprocs=world,
+             join=True)
+    assert sorted(ret.keys()) == list(range(world))
+    for r in range(1, world):
+        assert np.array_equal(ret[0][0], ret[r][0]) and np.array_equal(ret[0][1], ret[r][1]), \
+            "ranks must agree bitwise"
+        assert ret[r][2] == ret[0][2]
+    return ret[0]
 
 
 @pytest.mark.gpu
@@ -147,19 +163,31 @@ def test_two_processes_sharing_one_gpu_equal_single_engine(gpu):
     (solve_local / finish) and must reproduce the single-engine solve of the whole batch."""
     from mppi_gpu_amd import PointMassModel
     K, A, T, seed, world = 5001, 2, 200, 23, 2
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = 29700 + (os.getpid() % 2000)
-    mp.spawn(_gpu_worker, args=(world, port, K, A, T, seed, ret), nprocs=world, join=True)
-    acts0, U0 = ret[0]
-    acts1, U1 = ret[1]
-    assert np.array_equal(acts0, acts1) and np.array_equal(U0, U1), "ranks must agree bitwise"
+    acts0, U0, tr = _run_gpu_ranks(world, K, A, T, seed, "collective", 29700)
+    assert tr == "collective"
     case = ol.make_case(A, 1, T, seed=5, u_scale=0.03)
     with PointMassModel(K, T, float(case["dt"]), 2 * A, A) as m:
         m.set_seed(seed)
         m.memcpy_set_data(case["x0"], case["U"], case["goal"], case["w"])
-        for it in range(3):
+        for it in range(4):
+            if it == 3:
+                m.set_x(case["x0"] * 0.5)
             a = m.get_act()
             scale = max(float(np.abs(m.get_u()).max()), 0.025)
             assert np.abs(a - acts0[it]).max() <= 2e-6 * scale, it
         assert np.abs(m.get_u() - U0).max() <= 5e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,K,A,T", [(2, 5001, 2, 200), (3, 4000, 3, 50)])
+def test_direct_peer_exchange_equals_collective_bitwise(gpu, world, K, A, T):
+    """The direct exchange (hipIpc-mapped inboxes, tagged 8-byte words written by the combine
+    kernel of one PROCESS and polled by the combine kernel of another) must give the bits of
+    local combine + all-gather + finish, on every rank; "auto" must have validated and kept it."""
+    seed = 31
+    acts_c, U_c, tr_c = _run_gpu_ranks(world, K, A, T, seed, "collective", 31700)
+    acts_d, U_d, tr_d = _run_gpu_ranks(world, K, A, T, seed, "direct", 33700)
+    acts_a, U_a, tr_a = _run_gpu_ranks(world, K, A, T, seed, "auto", 35700)
+    assert (tr_c, tr_d, tr_a) == ("collective", "direct", "direct")
+    assert np.array_equal(acts_c, acts_d) and np.array_equal(U_c, U_d)
+    assert np.array_equal(acts_c, acts_a) and np.array_equal(U_c, U_a)

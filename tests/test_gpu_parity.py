@@ -359,6 +359,84 @@ def test_sharded_engines_equal_single_engine(gpu):
         s.close()
 
 
+@pytest.mark.gpu
+def test_direct_exchange_in_process_equals_gathered_finish(gpu):
+    """Three shard engines in ONE process, each on its own stream, exchanging through their
+    inboxes (raw pointers instead of ipc handles) == local combine + gather + finish, bit for bit.
+    The three combine kernels wait for one another, so they must be resident together: separate
+    non-blocking streams; the exchange time-out turns a scheduling surprise into an error."""
+    import torch
+    from mppi_gpu_amd import PointMassModel
+    A, K, T, G = 2, 6000, 120, 3
+    c = ol.make_case(A, K, T, seed=61)
+    bounds = [0, 2100, 4000, K]
+
+    def make():
+        out = []
+        for g in range(G):
+            s = PointMassModel(bounds[g + 1] - bounds[g], T, float(c["dt"]), 2 * A, A,
+                               k_offset=bounds[g])
+            s.set_seed(9)
+            s.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            out.append(s)
+        return out
+
+    ref = make()
+    L = ref[0].partial_len()
+    ref_acts = []
+    for it in range(3):
+        gathered = torch.zeros(G, L, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        for g, s in enumerate(ref):
+            s.solve_local_async(gathered[g].data_ptr())
+            s.sync_act()
+        for s in ref:
+            s.solve_finish_async(gathered.data_ptr(), G)
+        ref_acts.append([s.sync_act() for s in ref][0])
+    U_ref = ref[0].get_u()
+    for s in ref:
+        s.close()
+
+    eng = make()
+    ptrs = [s.xchg_open(g, G)[1] for g, s in enumerate(eng)]
+    for s in eng:
+        s.xchg_connect(same_process=ptrs)
+        s.xchg_set_timeout(5.0)
+    for it in range(3):
+        for s in eng:
+            s.solve_exchange_async()          # each on its engine's own stream
+        acts = [s.sync_act() for s in eng]
+        for a in acts:
+            assert np.array_equal(a, ref_acts[it]), it
+    for s in eng:
+        assert np.array_equal(s.get_u(), U_ref)
+        s.close()
+
+
+@pytest.mark.gpu
+def test_direct_exchange_times_out_instead_of_hanging(gpu):
+    """A rank whose peer never shows up gives up after the time-out and reports it; the engine
+    stays usable for ordinary solves."""
+    import torch
+    from mppi_gpu_amd import PointMassModel
+    A, K, T = 2, 2000, 50
+    c = ol.make_case(A, K, T, seed=62)
+    with PointMassModel(K, T, float(c["dt"]), 2 * A, A) as m:
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        _, mine = m.xchg_open(0, 2)
+        W = ((T * A + 2 + 15) // 16) * 16
+        silent = torch.zeros(2 * 2 * W, dtype=torch.int64, device="cuda")   # rank 1 never writes
+        torch.cuda.synchronize()
+        m.xchg_connect(same_process=[mine, silent.data_ptr()])
+        m.xchg_set_timeout(0.3)
+        m.solve_exchange_async()
+        with pytest.raises(RuntimeError, match="timed out"):
+            m.sync_act()
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        a = m.get_act()
+        assert np.all(np.isfinite(a))
+
+
 # ---- BASELINE.json full sizes: size-independent properties + oracle on the device's noise ----
 
 FULL = [(2, 10_000, 200), (3, 100_000, 200)]
