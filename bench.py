@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--transport", choices=("auto", "direct", "collective"), default="auto",
                     help="rank-partial exchange of the sharded solve: direct peer stores, RCCL "
                          "all-gather, or auto (direct if it validates against the collective)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="analysis: all ranks share cuda:0 and torch.distributed runs over gloo "
+                         "(RCCL wants one GPU per rank); exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (local solve, RCCL all-gather, finish) even "
                          "with one rank: rehearsal of the N > 1 path on a one-GPU box")
@@ -105,6 +108,8 @@ def main():
     if world != N:
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if N > 1 or args.force_sharded:
@@ -113,7 +118,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     A, K, T, desc = WORKLOADS[args.workload]
     c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)      # x0 ~ 0.1 N(0,1), U0 = 0, yaml goal/w
@@ -153,7 +161,8 @@ def main():
     fence()
     dt_s = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt_s], device="cpu" if args.rehearse_one_gpu else "cuda",
+                          dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_s = float(tt.item())
     act = m.sync_act()
@@ -188,7 +197,9 @@ def main():
             "value": value, "unit": "rollouts/s", "n_gpus": N, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt_s / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" if not args.inject else "INVALID: injected zero noise (analysis run)",
+            "data": ("INVALID: injected zero noise (analysis run)" if args.inject else
+                     "INVALID: all ranks on one GPU (rehearsal)" if args.rehearse_one_gpu else
+                     "synthetic"),
             "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
                        "global_rollouts": N * K, "sharding": f"samples x{N}",
                        "exchange": None if sharded is None else
