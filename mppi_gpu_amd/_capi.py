@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmppi_gpu_amd.so")
+# MPPI_GPU_AMD_LIB: analysis builds of the same library (tools/trace_regions.py), never a fallback
+LIB_PATH = os.environ.get("MPPI_GPU_AMD_LIB") or os.path.join(_HERE, "lib", "libmppi_gpu_amd.so")
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)

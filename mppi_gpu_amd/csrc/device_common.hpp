@@ -1,34 +1,54 @@
 // device_common.hpp -- device-side building blocks shared by the rollout kernels:
-// counter-addressed rocRAND Philox, the hardware Box-Muller, DPP / lane-swap reductions, the
+// counter-addressed Philox4x32-10 (rocRAND's stream), the hardware Box-Muller, DPP / lane-swap reductions, the
 // reference's step and cost arithmetic, and the per-block running (min, exp-sum, sums) fold.
 #pragma once
 #include "kernels.hpp"
 
-#include <rocrand/rocrand_kernel.h>
 
 namespace mppi {
 
 
 // ------------------------------------------------------------------------------------------
-// rocRAND Philox4x32-10, addressed by counter.  ten_rounds() is a protected member of
-// rocRAND's engine; deriving from it lets a lane evaluate block (counter, key) directly
-// -- random access in (sample, time) with no stored generator state.  Identical words to
-// rocrand_init(seed, subsequence = k, offset = 4*block) + rocrand4() (tests check this).
-// ------------------------------------------------------------------------------------------
-struct PhiloxAt : public rocrand_device::philox4x32_10_engine {
+// Philox4x32-10 addressed by counter: a lane evaluates block (counter, key) directly -- random
+// access in (sample, time) with no stored generator state.  Identical words to rocRAND's
+// rocrand_init(seed, subsequence = k, offset = 4*block) + rocrand4() (tests check this against
+// the rocRAND host API and the Random123 known answer).
+//
+// The ten rounds are written out for gfx950 (Salmon et al., "Parallel random numbers: as easy as
+// 1, 2, 3", SC'11: multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 /
+// 0xBB67AE85): per round two v_mad_u64_u32 (each yields the high AND the low product word) and
+// two v_bitop3_b32 with truth table 0x96 = a ^ b ^ c, a gfx950 instruction hipcc does not form
+// from `hi ^ ctr ^ key` by itself (it emits two v_xor_b32 each; rocRAND's ten_rounds compiles to
+// 6 VALU per round, this to 4).  The round keys are wave-uniform and stay in SGPRs.
+struct PhiloxAt {
+    __device__ __forceinline__ static unsigned int xor3(unsigned int a, unsigned int b,
+                                                        unsigned int c)
+    {
+        return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    }
     __device__ __forceinline__ static uint4 block(unsigned long long blk, unsigned long long k,
                                                   unsigned long long seed)
     {
-        PhiloxAt eng;
-        uint4 ctr;
-        ctr.x = static_cast<unsigned int>(blk);
-        ctr.y = static_cast<unsigned int>(blk >> 32);
-        ctr.z = static_cast<unsigned int>(k);
-        ctr.w = static_cast<unsigned int>(k >> 32);
-        uint2 key;
-        key.x = static_cast<unsigned int>(seed);
-        key.y = static_cast<unsigned int>(seed >> 32);
-        return eng.ten_rounds(ctr, key);
+        unsigned int c0 = static_cast<unsigned int>(blk);
+        unsigned int c1 = static_cast<unsigned int>(blk >> 32);
+        unsigned int c2 = static_cast<unsigned int>(k);
+        unsigned int c3 = static_cast<unsigned int>(k >> 32);
+        unsigned int k0 = static_cast<unsigned int>(seed);
+        unsigned int k1 = static_cast<unsigned int>(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+            const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+            const unsigned int n0 = xor3(static_cast<unsigned int>(p1 >> 32), c1, k0);
+            const unsigned int n2 = xor3(static_cast<unsigned int>(p0 >> 32), c3, k1);
+            c1 = static_cast<unsigned int>(p1);
+            c3 = static_cast<unsigned int>(p0);
+            c0 = n0;
+            c2 = n2;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
     }
 };
 
@@ -41,8 +61,9 @@ struct PhiloxAt : public rocrand_device::philox4x32_10_engine {
 __device__ __forceinline__ void box_muller_hw(unsigned int x, unsigned int y, float& z0, float& z1)
 {
     const float kInv = 2.3283064e-10f;                       // 2^-32
-    const float u = kInv + (float)x * kInv;                  // (0, 1]
-    const float th = kInv + (float)y * kInv;                 // (0, 1] revolutions
+    // x * 2^-32 is exact, so the fused form below rounds exactly like kInv + x * kInv
+    const float u = fmaf((float)x, kInv, kInv);              // (0, 1]
+    const float th = fmaf((float)y, kInv, kInv);             // (0, 1] revolutions
     const float r2 = -1.3862943611198906f * __builtin_amdgcn_logf(u);
     const float s = __builtin_amdgcn_sqrtf(r2);
     z0 = __builtin_amdgcn_sinf(th) * s;

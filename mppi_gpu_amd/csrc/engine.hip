@@ -55,6 +55,22 @@ int ilog2(int x)
 
 }  // namespace
 
+#ifdef MPPI_TRACE
+unsigned long long* mppi::g_mppi_trace_buf = nullptr;
+extern "C" int mppi_debug_trace(unsigned long long* out, int n_blocks)
+{   // analysis builds: allocate on first call (out == null), else copy the stamps back
+    const size_t bytes = (size_t)mppi::kMaxParts * 16 * sizeof(unsigned long long);
+    if (!mppi::g_mppi_trace_buf) {
+        if (hipMalloc(&mppi::g_mppi_trace_buf, bytes) != hipSuccess) return -1;
+        (void)hipMemset(mppi::g_mppi_trace_buf, 0, bytes);
+    }
+    if (!out) return 0;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, mppi::g_mppi_trace_buf, (size_t)n_blocks * 16 * sizeof(unsigned long long),
+                     hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 struct mppi_engine {
     // problem
     int K = 0, T = 0, S = 0, A = 0, TA = 0, SG = 0, BPG = 0, NGT = 0, NBT = 0;

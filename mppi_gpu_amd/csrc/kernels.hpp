@@ -77,7 +77,19 @@ struct RolloutHot {
     int K, T, TA, NBT, NBTp;
     int logC, ng, nq, L, c_last, n_last, n_tileblk;
     float x0[8];
+#ifdef MPPI_TRACE      // analysis builds only (tools/trace.sh): per-block region time stamps
+    unsigned long long* trace;
+#endif
 };
+#ifdef MPPI_TRACE
+extern unsigned long long* g_mppi_trace_buf;     // [kMaxParts][16], engine.hip
+#define MPPI_STAMP(i)                                                                    \
+    do {                                                                                 \
+        if (h.trace && threadIdx.x == 0) h.trace[(size_t)blockIdx.x * 16 + (i)] = clock64(); \
+    } while (0)
+#else
+#define MPPI_STAMP(i) do { } while (0)
+#endif
 
 inline RolloutHot make_hot(const RolloutArgs& a)
 {
@@ -92,6 +104,9 @@ inline RolloutHot make_hot(const RolloutArgs& a)
     h.logC = a.logC; h.ng = a.ng; h.nq = a.nq; h.L = a.L;
     h.c_last = a.c_last; h.n_last = a.n_last; h.n_tileblk = a.n_tileblk;
     for (int i = 0; i < 8; ++i) h.x0[i] = a.x0[i];
+#ifdef MPPI_TRACE
+    h.trace = g_mppi_trace_buf;
+#endif
     if (const char* dbg = getenv("MPPI_DEBUG_SKIP")) {   // latency probes, never set in production
         h.n_tileblk = 0;                                 // 1: prologue + epilogue only
         if (dbg[0] == '2') { h.NBTp = 0; h.TA = 0; }     // 2: (almost) empty kernel

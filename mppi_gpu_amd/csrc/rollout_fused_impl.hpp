@@ -62,6 +62,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane & (C - 1);
+    MPPI_STAMP(0);
 
     // ---- issue the loads of the nominal controls and of the cold constants; they complete
     //      while the first tile's Philox blocks are computed ----------------------------------
@@ -142,7 +143,9 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
                 }
             }
         }
+        if (first) MPPI_STAMP(1);
         if (first) __syncthreads();      // U and lambda*inv_s*U are in LDS from here on
+        if (first) MPPI_STAMP(2);
 
         // ---- pass 1b: the chunk's zero-state response is two weighted sums of a = u + e:
         //      V = dt*S1,  P = B0*S1 + dt^2*((L-1)*S1 - S2),  S1 = sum a_j, S2 = sum j*a_j.
@@ -211,6 +214,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
                 MPPI_COMBINE((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
 #undef MPPI_COMBINE
         }
+        if (first) MPPI_STAMP(3);
         float p[A], v[A];
         {
             const float tau0 = (float)nbefore * P.dt;
@@ -297,6 +301,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             }
             cpart = (c < c_last) ? cpart : (c == c_last ? cT + fc : 0.0f);
         }
+        if (first) MPPI_STAMP(4);
         const float cost = group_sum<LOGC>(cpart);
         if (valid && c == 0) cost_out[kloc] = cost;
 
@@ -307,6 +312,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             const float sw = wave_sum(c == 0 ? wt : 0.0f);
             if (lane == 0) misc[4 + wave] = sw;
         }
+        if (first) MPPI_STAMP(5);
         const float wtN = ((long long)kglob < k_cover) ? wt : 0.0f;
         float* wrow = wsum + wave * TAp + (c * nq) * 4;
 #pragma unroll
@@ -322,11 +328,15 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
                 }
             }
         }
+        if (first) MPPI_STAMP(6);
         __syncthreads();
+        if (first) MPPI_STAMP(7);
         fold_tile(rs, m_t, misc, wsum, nrun, TAp, TA, inv_lambda, first);
+        if (first) MPPI_STAMP(8);
         first = false;
         __syncthreads();
     }
+    MPPI_STAMP(9);
 
     // ---- publish the block partial ----------------------------------------------------------
     float* Nout = g.part_N + (size_t)blockIdx.x * TA;
@@ -335,6 +345,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         g.part_m[blockIdx.x] = rs.M;
         g.part_s[blockIdx.x] = rs.S;
     }
+    MPPI_STAMP(10);
 }
 
 // Occupancy target: the kernel is VALU-issue / latency bound, so 4 waves per SIMD (<= 128 VGPRs)
