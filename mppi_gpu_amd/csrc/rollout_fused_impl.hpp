@@ -116,12 +116,17 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         float* etile = Eint + ((tile * nq) * 64 + lane) * 4;      // + q*256 floats per block
 
         // ---- pass 1a: draw (or load) the chunk's noise into registers and store it ----------
+        // `gi < ng` is wave-uniform.  Left to itself hipcc hoists the NG comparisons out of the tile
+        // loop as lane masks and re-tests each with a v_cndmask + v_cmp pair (VALU, the bound
+        // resource); an opaque scalar copy per pass keeps them s_cmp + s_cbranch.
+        int ngs = ng;
+        asm volatile("" : "+s"(ngs));
         float e[NE];
         // (groups gi >= ng of a template larger than the chunk are never read: every use below
         //  sits under the same wave-uniform `gi < ng`, so e[] needs no initialisation)
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            if (gi < ng) {
+            if (gi < ngs) {
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
                     const int q = gi * BPG + j;
@@ -151,11 +156,12 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         //      V = dt*S1,  P = B0*S1 + dt^2*((L-1)*S1 - S2),  S1 = sum a_j, S2 = sum j*a_j.
         //      No masking: what a partial or empty chunk adds past the horizon is not used. ---
         float S1[A], S2[A];
+        asm volatile("" : "+s"(ngs));
 #pragma unroll
         for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            if (gi < ng) {
+            if (gi < ngs) {
                 float u[BPG * 4];
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
@@ -241,11 +247,12 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         //      snapshot (cost so far, state) at the wave-uniform step n_last and uses that. ----
         float cpart = 0.0f, cT = 0.0f;
         float pT[A], vT[A];
+        asm volatile("" : "+s"(ngs));
 #pragma unroll
         for (int i = 0; i < A; ++i) { pT[i] = 0.f; vT[i] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            if (gi < ng) {
+            if (gi < ngs) {
                 float u[BPG * 4], uc[BPG * 4];
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
@@ -315,9 +322,10 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
         if (first) MPPI_STAMP(5);
         const float wtN = ((long long)kglob < k_cover) ? wt : 0.0f;
         float* wrow = wsum + wave * TAp + (c * nq) * 4;
+        asm volatile("" : "+s"(ngs));
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            if (gi < ng) {
+            if (gi < ngs) {
 #pragma unroll
                 for (int j = 0; j < BPG; ++j) {
                     const int q = gi * BPG + j;
