@@ -78,9 +78,13 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="draw each solve's noise one solve ahead inside the combine launch "
-                         "(measured slower; default is in-place sampling)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=(0, 1, 2),
+                    help="mppi_set_pipeline mode: 0 deferred combine (default: back-to-back solves "
+                         "are one launch each), 1 noise prefetch (experiment), 2 eager (rollout + "
+                         "combine launch per solve)")
+    ap.add_argument("--blocking", action="store_true",
+                    help="analysis: every step is a blocking get_act (the closed-loop call), not an "
+                         "asynchronous solve")
     ap.add_argument("--transport", choices=("auto", "direct", "collective"), default="auto",
                     help="rank-partial exchange of the sharded solve: direct peer stores, RCCL "
                          "all-gather, or auto (direct if it validates against the collective)")
@@ -142,6 +146,8 @@ def main():
     if args.inject:
         m.set_noise(np.zeros((K, T, A), np.float32))
     step = m.solve_async if sharded is None else sharded.solve_async
+    if args.blocking:
+        step = m.get_act if sharded is None else sharded.get_act
 
     def fence():
         if dist is not None:

@@ -104,14 +104,20 @@ int mppi_set_ref_compat(mppi_engine* e, int on);
  * anchor.  max_blocks caps the persistent grid (0 = auto). */
 int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
 
-/* Pipelined noise generation (default OFF): the blocks of solve j's combine launch that are not
- * needed for combining draw the Philox / Box-Muller noise of solve j+1 into a second buffer; the
- * rollout of j+1 then reads its noise instead of drawing it.  Same noise values either way (the
- * stream is a pure function of seed, solve index, sample and time).  Off = the rollout draws its
- * noise in place.  Measured on MI355X: the stand-alone Philox/Box-Muller
- * pass costs 7.8 us at K = 1e4 (2-D) -- more than the 5.4 us combine it hides under and more than
- * the 4.5 us it removes from the rollout -- so in-place sampling is the default. */
-int mppi_set_pipeline(mppi_engine* e, int on);
+/* How consecutive solves are enqueued (results are identical in every mode):
+ *   0  deferred combine (default).  mppi_solve_async launches the rollout only; the combine
+ *      (beta, nabla, update, shift, action) is launched by whatever comes next: if that is another
+ *      mppi_solve_async on the same stream, it RIDES in that launch -- the first blocks of the
+ *      grid play the combine role while the rollout blocks draw their Philox / Box-Muller noise
+ *      (half of the kernel, and independent of the controls), and each rollout block waits on an
+ *      agent-scope counter for the finished controls before it stages them; anything that needs
+ *      the results (mppi_sync_act, mppi_get_act, mppi_get_u, mppi_get_inf, mppi_set_data, ...)
+ *      flushes it as a stand-alone launch first.  mppi_get_act alone is therefore the same two
+ *      launches as mode 2; back-to-back solves become ONE launch each.
+ *   1  noise prefetch (experiment, slower on MI355X: DESIGN.md section 2): the combine launch of
+ *      solve j also draws the noise of solve j+1 into a second buffer.
+ *   2  eager: every solve launches its rollout and its combine at once. */
+int mppi_set_pipeline(mppi_engine* e, int mode);
 
 /* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */
 

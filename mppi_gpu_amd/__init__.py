@@ -162,8 +162,9 @@ class PointMassModel:
     def set_tuning(self, chunks=0, strict=False, max_blocks=0):
         check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
 
-    def set_pipeline(self, on):
-        check(self._lib.mppi_set_pipeline(self._h, int(bool(on))))
+    def set_pipeline(self, mode):
+        """0 deferred combine (default), 1 noise prefetch (experiment), 2 eager; see the header."""
+        check(self._lib.mppi_set_pipeline(self._h, int(mode)))
 
     def geometry(self):
         g = (C.c_int * 5)()

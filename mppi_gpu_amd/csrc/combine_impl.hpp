@@ -1,0 +1,354 @@
+// combine_impl.hpp -- the combine step as a device function generic in the block size, shared by
+// the stand-alone k_combine launch (1024 threads, kernels.hip), the stand-alone 256-thread launch
+// and the combine ROLE inside the fused rollout launch (rollout_fused_impl.hpp), which must give
+// equal bits.
+#pragma once
+#include "device_common.hpp"
+
+namespace mppi {
+
+struct CombineSmem {     // LDS of one combine block; carve from static or dynamic shared memory
+    float* r;            // [kMaxParts]
+    float* red;          // [(THREADS/64) * 4 * kCombineCols]
+    float* scal;         // [2 * THREADS/64]
+    int* flag;           // [1]
+};
+template <int THREADS>
+constexpr int combine_smem_floats()
+{
+    return kMaxParts + (THREADS / 64) * 4 * kCombineCols + 2 * (THREADS / 64) + 1;
+}
+template <int THREADS>
+__device__ __forceinline__ CombineSmem carve_combine_smem(float* base)
+{
+    CombineSmem s;
+    s.r = base;
+    s.red = s.r + kMaxParts;
+    s.scal = s.red + (THREADS / 64) * 4 * kCombineCols;
+    s.flag = reinterpret_cast<int*>(s.scal + 2 * (THREADS / 64));
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Combine: beta (src/point_mass.cu:273-322), nabla (:328-377), weighted update
+// (:384-480), action read-out and shift (:195-199, :805-824) in one launch.
+//
+// Grid = (ceil(TA/16) column blocks) x (RS row splits), 1024 threads.  Every block recomputes
+// beta and nabla from the (<= kMaxParts) partial minima / exp-sums in a fixed order, then sums
+// ITS rows of the weighted-noise partials for ITS 16 columns, all row loads in flight, four
+// rows per wave-instruction.  With RS > 1 the splits meet through a per-column-block ticket: each
+// stores its 64 sums, releases at agent scope and takes a ticket; the block that draws the
+// last ticket acquires and adds the RS slabs IN SPLIT ORDER (so the result does not depend on
+// arrival order) and applies the update.  The ticket is zero at creation and reset by the
+// last arriver.
+// ------------------------------------------------------------------------------------------
+// ---- rank-partial exchange words (XchgArgs) -------------------------------------------------
+__device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigned int tag)
+{
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Poll inbox word p1 (and p2 when non-null, both loads in flight together) until they carry
+// `tag`; bounded by the exchange time-out so that every wave reaches its exit whatever the
+// peers do.
+__device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const unsigned long long* p2,
+                                         unsigned int tag, unsigned long long limit, float& v1,
+                                         float& v2, int& timed_out)
+{
+    const unsigned long long t0 = wall_clock64();
+    bool ok1 = (p1 == nullptr), ok2 = (p2 == nullptr);
+    v1 = 0.0f;
+    v2 = 0.0f;
+    for (;;) {
+        unsigned long long w1 = 0, w2 = 0;
+        if (!ok1) w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok2) w2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok1 && (unsigned int)(w1 >> 32) == tag) {
+            v1 = __uint_as_float((unsigned int)w1);
+            ok1 = true;
+        }
+        if (!ok2 && (unsigned int)(w2 >> 32) == tag) {
+            v2 = __uint_as_float((unsigned int)w2);
+            ok2 = true;
+        }
+        if (ok1 && ok2) return;
+        if (wall_clock64() - t0 > limit) {
+            timed_out = 1;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// The update of one control value: the same expression wherever it is evaluated (combine blocks,
+// rollout blocks that rebuild the controls from the tagged split sums), hence the same bits.
+__device__ __forceinline__ float updated_control(float uin, float tot, float nabla)
+{
+    return uin + tot / nabla;
+}
+
+// Write column n of the updated, shifted controls (and the action).
+__device__ __forceinline__ void publish_control(const CombineArgs& a, int n, float unew)
+{
+    float* Uout = a.U + (size_t)((a.solve_idx + 1ull) & 1ull) * a.TA;
+    if (n < a.A) {
+        a.act_dev[n] = unew;
+        if (a.act_host) a.act_host[n] = unew;
+    } else {
+        Uout[n - a.A] = unew;
+    }
+    if (n >= a.TA - a.A) Uout[n] = unew;       // last step repeated
+}
+
+// Final combine of G rank partials held in LDS (xm[g], xs[g], xv[g][col]), rank order, one
+// thread per column; shared by the direct exchange and by the gathered (RCCL) path.
+__device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int tid, int G,
+                                               const float* xm, const float* xs, const float* xv,
+                                               float uin)
+{
+    if (tid >= kCombineCols) return;
+    const int n = cb * kCombineCols + tid;
+    float beta = xm[0];
+    for (int g = 1; g < G; ++g) beta = fminf(beta, xm[g]);
+    float nabla = 0.0f, tot = 0.0f;
+    for (int g = 0; g < G; ++g) {
+        const float r = (xm[g] < INFINITY) ? expf(-a.inv_lambda * (xm[g] - beta)) : 0.0f;
+        nabla = fmaf(r, xs[g], nabla);
+        tot = fmaf(r, xv[g * kCombineCols + tid], tot);
+    }
+    if (n < a.TA) publish_control(a, n, updated_control(uin, tot, nabla));
+    if (cb == 0 && tid == 0) {
+        a.dev->beta = beta;
+        a.dev->nabla = nabla;
+    }
+}
+
+__device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float uin, float tot,
+                                              float nabla)
+{
+    if (a.final_mode) {
+        const float unew = updated_control(uin, tot, nabla);
+        publish_control(a, n, unew);
+        if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+    } else {
+        a.partial_out[2 + n] = tot;
+    }
+}
+
+// One combine block: column block cb = bid % n_cols, row split rs = bid / n_cols.
+template <int THREADS, int NR>    // NR row loads in flight per lane
+__device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, const CombineSmem& sm)
+{
+    constexpr int NW = THREADS / 64;                  // waves per block
+    constexpr int RPW = 64 / kCombineCols;            // rows per wave-instruction
+    constexpr int NRG = NW * RPW;                     // row groups per block
+    float* const r_lds = sm.r;                        // [kMaxParts]
+    float* const red = sm.red;                        // [NRG * kCombineCols]
+    float* const scal = sm.scal;                      // [2 * NW]
+    volatile int& last_flag = *sm.flag;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;   // 0..NW-1
+    const int cb = bid % a.n_cols;
+    const int rs = bid / a.n_cols;
+    const int RS = a.RS;
+    constexpr int PT = kMaxParts / THREADS;           // partials per thread
+
+    // rows of this split
+    const int per = (a.n_parts + RS - 1) / RS;
+    const int p_begin = rs * per;
+    const int p_end = min(a.n_parts, p_begin + per);
+    const int col = lane & (kCombineCols - 1);
+    const int rgrp = wave * RPW + lane / kCombineCols;   // 0..NRG-1
+    const int n = cb * kCombineCols + col;
+
+    // ---- every global load this block needs is issued up front: the partial minima and
+    //      exp-sums, the first batch of weighted-noise rows and the nominal control; beta,
+    //      nabla and the rescale factors are computed while they are in flight -------------
+    float mreg[PT], sreg[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int p = tid + j * THREADS;
+        mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
+        sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
+    }
+    float v[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int p = p_begin + rgrp + NRG * j;
+        v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
+    }
+    float uin = 0.0f;
+    if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
+
+    float mloc = mreg[0];
+#pragma unroll
+    for (int j = 1; j < PT; ++j) mloc = fminf(mloc, mreg[j]);
+    mloc = wave_min(mloc);
+    if (lane == 0) scal[wave] = mloc;
+    __syncthreads();
+    float beta = scal[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) beta = fminf(beta, scal[i]);
+
+    float sloc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int p = tid + j * THREADS;
+        const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
+        if (p < a.n_parts) r_lds[p] = r;
+        sloc += r * sreg[j];
+    }
+    sloc = wave_sum(sloc);
+    if (lane == 0) scal[NW + wave] = sloc;
+    __syncthreads();
+    float nabla = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) nabla += scal[NW + i];
+
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int p = p_begin + rgrp + NRG * j;
+        if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
+    }
+    if (n < a.TA) {      // rows beyond the first batch (only when RS hit its cap)
+        for (int p0 = p_begin + rgrp + NRG * NR; p0 < p_end; p0 += NRG * NR) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int p = p0 + NRG * j;
+                v[j] = (p < p_end) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int p = p0 + NRG * j;
+                if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
+            }
+        }
+    }
+    red[rgrp * kCombineCols + col] = acc;
+    __syncthreads();
+    float tot = 0.0f;
+    if (wave == 0) {       // both halves of the wave compute the same 32 sums, in row-group order
+#pragma unroll
+        for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
+    }
+
+    // `mine`: this rank's finished sums for the block's 16 columns (threads 0..15 of the block
+    // that applies them); apply_blk is block-uniform
+    float mine = tot;
+    bool apply_blk = true;
+    if (a.slab_tag) {
+        // Fence-free meeting of the row splits (the 256-thread shape, which may run inside a busy
+        // rollout launch): splits 0 .. RS-2 publish their sums as tagged 8-byte words and are done;
+        // the LAST split (highest block index, so everything it waits for was dispatched before
+        // it) polls them, adds them in split order with its own sum last, and applies.
+        const unsigned int tag = a.tag;
+        if (rs != RS - 1) {
+            if (tid < kCombineCols && n < a.TA)
+                ll_store(a.slab_tag + (size_t)rs * a.TA + n, tot, tag);
+            return;
+        }
+        if (RS > 1 && tid < kCombineCols && n < a.TA) {
+            float t2 = 0.0f;
+            int timed_out = 0;
+            for (int q0 = 0; q0 < RS - 1; q0 += 2) {
+                const unsigned long long* p1 = a.slab_tag + (size_t)q0 * a.TA + n;
+                const unsigned long long* p2 = (q0 + 1 < RS - 1) ? p1 + a.TA : nullptr;
+                float v1, v2;
+                ll_poll2(p1, p2, tag, a.x.timeout_ticks, v1, v2, timed_out);
+                t2 += v1;
+                if (p2) t2 += v2;
+            }
+            mine = t2 + tot;
+            if (timed_out) {
+                *a.x.err_dev = 2;
+                if (a.x.err_host) *a.x.err_host = 2;
+            }
+        }
+    } else if (RS > 1) {
+        // publish this split's 64 sums, then take a ticket (guide: agent-scope release before
+        // the counter, agent-scope acquire in the last arriver, waits written out by hand)
+        if (tid < kCombineCols && n < a.TA) a.slab[(size_t)rs * a.TA + n] = tot;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int old = __hip_atomic_fetch_add(&a.tickets[cb], 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (old == (unsigned int)(RS - 1));
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&a.tickets[cb], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last_flag = is_last;
+        }
+        __syncthreads();
+        apply_blk = last_flag != 0;
+        if (apply_blk && tid < kCombineCols && n < a.TA) {
+            float t2 = 0.0f;
+            for (int q = 0; q < RS; ++q)
+                t2 += __hip_atomic_load(&a.slab[(size_t)q * a.TA + n], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+            mine = t2;
+        }
+    }
+    if (a.final_mode != 2) {
+        if (apply_blk && tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, mine, nabla);
+        if (cb == 0 && rs == RS - 1 && tid == 0) {
+            if (a.final_mode) {
+                a.dev->beta = beta;
+                a.dev->nabla = nabla;
+            } else {
+                a.partial_out[0] = beta;
+                a.partial_out[1] = nabla;
+            }
+        }
+        return;
+    }
+    if (!apply_blk) return;
+
+    // ---- direct exchange: send this rank's partial to every inbox, collect all G, finish ----
+    const XchgArgs& x = a.x;
+    float* xv = r_lds;                                   // [G][16]   (r_lds is free by now)
+    float* xm = r_lds + kMaxRanks * kCombineCols;        // [G]
+    float* xs = xm + kMaxRanks;                          // [G]
+    float* mine_lds = xs + kMaxRanks;                    // [16]
+    __syncthreads();
+    if (tid < kCombineCols) mine_lds[tid] = (n < a.TA) ? mine : 0.0f;
+    __syncthreads();
+    const int c = tid & (kCombineCols - 1);
+    const int nn = cb * kCombineCols + c;
+    const size_t slot_w = (size_t)x.W;
+    constexpr int GPB = THREADS / kCombineCols;          // peers served per sweep of the block
+    for (int g = tid / kCombineCols; g < x.G; g += GPB) {   // g: peer this thread talks to
+        unsigned long long* dst = x.peers[g] + ((size_t)x.parity * x.G + x.rank) * slot_w;
+        if (nn < a.TA) ll_store(dst + 2 + nn, mine_lds[c], x.tag);
+        if (cb == 0 && c == 0) {
+            ll_store(dst + 0, beta, x.tag);
+            ll_store(dst + 1, nabla, x.tag);
+        }
+    }
+    int timed_out = 0;
+    for (int g = tid / kCombineCols; g < x.G; g += GPB) {
+        const unsigned long long* src = x.peers[x.rank] + ((size_t)x.parity * x.G + g) * slot_w;
+        float v1, v2;   // column word of rank g; columns 0 / 1 also fetch beta_g / S_g
+        ll_poll2((nn < a.TA) ? src + 2 + nn : nullptr, (c < 2) ? src + c : nullptr, x.tag,
+                 x.timeout_ticks, v1, v2, timed_out);
+        xv[g * kCombineCols + c] = v1;
+        if (c == 0) xm[g] = v2;
+        if (c == 1) xs[g] = v2;
+    }
+    if (timed_out) {
+        *x.err_dev = 1;
+        if (x.err_host) *x.err_host = 1;
+    }
+    __syncthreads();
+    finish_columns(a, cb, tid, x.G, xm, xs, xv, uin);
+}
+
+}  // namespace mppi

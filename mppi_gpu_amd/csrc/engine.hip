@@ -133,16 +133,29 @@ struct mppi_engine {
     unsigned long long** d_xg_peers = nullptr;         // device table of the G inbox bases
     unsigned long long xg_seq = 0;                     // exchanges done; never reset
     double xg_timeout_s = 5.0;
-    int* d_xg_err = nullptr;
-    int* h_xg_err = nullptr;                           // pinned + mapped
-    int* h_xg_err_dev = nullptr;
 
     // profiling
     int prof = 0;                   // 0 = off, n = record every n-th solve
     bool prof_now = false;
     unsigned long long prof_count = 0;
-    std::vector<hipEvent_t> ev;     // 4 per profiled solve: rollout start/stop, combine start/stop
-    size_t ev_used = 0;
+    std::vector<hipEvent_t> ev[2];  // start/stop pairs: [0] rollout launches, [1] combine launches
+    size_t ev_used[2] = {0, 0};
+
+    // deferred combine (mppi_solve_async back to back): the combine of the last enqueued solve has
+    // not been launched yet; it rides at the front of the next solve's rollout launch, or is
+    // flushed by whatever needs its results
+    int defer = 1;                          // 0 = every solve launches its own combine
+    bool pending = false;
+    unsigned long long pending_idx = 0;     // solve index of the pending combine
+    hipStream_t pending_stream = nullptr;
+    unsigned long long* d_slab_tag = nullptr;   // [kMaxSmallSplits][TA] tagged split sums + nabla
+    unsigned int u_epoch = 0;               // combines launched through the small path; tag source
+    mppi::CombineArgs* d_cargs = nullptr;   // device copy of the riding combine's arguments
+    mppi::CombineArgs h_cargs_last;
+    bool cargs_valid = false;
+    int* d_err = nullptr;                   // device watchdog word: 1 = peer exchange timed out,
+    int* h_err = nullptr;                   // 2 = wait for a riding combine timed out
+    int* h_err_dev = nullptr;               // (pinned + mapped mirror the kernels also write)
 };
 
 namespace {
@@ -280,6 +293,9 @@ long long ref_cover(const mppi_engine_t* e)
 void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
 {
     a.dev = e->d_state;
+    a.fin_tag = e->d_slab_tag + (size_t)mppi::kMaxSmallSplits * e->TA;
+    a.err_dev = e->d_err;
+    a.err_host = e->h_err_dev;
     a.U = e->d_U;
     a.Eint = e->d_Eint;
     a.cost = e->d_cost;
@@ -313,20 +329,22 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
 }
 
 // a start/stop event pair for the next launch, or an empty timing when this solve is not sampled
-int prof_pair(mppi_engine_t* e, mppi::LaunchTiming& tm)
+int prof_pair(mppi_engine_t* e, mppi::LaunchTiming& tm, int which)
 {
     tm = mppi::LaunchTiming();
     if (!e->prof_now) return MPPI_OK;
-    if (e->ev_used + 2 > e->ev.size()) {
-        if (e->ev.size() >= 4 * 8192) return MPPI_OK;   // stop recording, keep running
+    std::vector<hipEvent_t>& ev = e->ev[which];
+    size_t& used = e->ev_used[which];
+    if (used + 2 > ev.size()) {
+        if (ev.size() >= 2 * 8192) return MPPI_OK;   // stop recording, keep running
         for (int i = 0; i < 2; ++i) {
             hipEvent_t ne;
             HIPCHK(hipEventCreate(&ne));
-            e->ev.push_back(ne);
+            ev.push_back(ne);
         }
     }
-    tm.start = e->ev[e->ev_used++];
-    tm.stop = e->ev[e->ev_used++];
+    tm.start = ev[used++];
+    tm.stop = ev[used++];
     return MPPI_OK;
 }
 
@@ -344,13 +362,72 @@ void fill_gen_args(const mppi_engine_t* e, mppi::GenArgs& ga, unsigned long long
     for (int i = 0; i < 4; ++i) ga.sigma[i] = e->sigma[i];
 }
 
-// sampling / rollout / per-block reduction
-int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
+// the final combine of solve `idx` over this engine's own block partials, in the 256-thread shape
+// that rides in a rollout launch or is flushed stand-alone
+void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long long idx,
+                      unsigned int tag)
+{
+    memset(&ca, 0, sizeof ca);
+    ca.dev = e->d_state;
+    ca.m = e->d_pm; ca.s = e->d_ps; ca.N = e->d_pN;
+    ca.m_stride = 1; ca.s_stride = 1; ca.N_stride = e->TA;
+    ca.n_parts = e->grid;
+    ca.TA = e->TA;
+    ca.A = e->A;
+    ca.inv_lambda = 1 / e->lambda;
+    ca.U = e->d_U;
+    ca.tag = tag;
+    ca.act_dev = e->d_act;
+    ca.act_host = e->h_act_dev;
+    ca.slab = e->d_slab;
+    ca.slab_tag = e->d_slab_tag;
+    ca.tickets = e->d_tickets;
+    ca.solve_idx = idx;
+    ca.final_mode = 1;
+    ca.x.timeout_ticks = 200000000ull;         // 2 s: bound on the split meeting's polls
+    ca.x.err_dev = e->d_err;
+    ca.x.err_host = e->h_err_dev;
+    const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
+    ca.row_splits = env ? atoi(env) : 0;
+    (void)mppi::combine_small_prepare(ca);
+}
+
+// launch the pending combine on its own (nothing to ride with)
+int flush_pending(mppi_engine_t* e)
+{
+    if (!e->pending) return MPPI_OK;
+    mppi::CombineArgs ca;
+    e->u_epoch += 1;
+    if (e->u_epoch == 0) e->u_epoch = 1;       // 0 is the tag of the zero-initialised buffer
+    fill_own_combine(e, ca, e->pending_idx, e->u_epoch);
+    mppi::LaunchTiming tm;
+    int rc = prof_pair(e, tm, 1);
+    if (rc) return rc;
+    e->pending = false;
+    HIPCHK(mppi::launch_combine_small(ca, e->pending_stream, tm));
+    return MPPI_OK;
+}
+
+// everything enqueued by this engine has run, nothing is pending
+int settle(mppi_engine_t* e)
+{
+    int rc = flush_pending(e);
+    if (rc) return rc;
+    if (e->last_stream && e->last_stream != e->stream) HIPCHK(hipStreamSynchronize(e->last_stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return MPPI_OK;
+}
+
+// sampling / rollout / per-block reduction; carry = let a pending combine ride in this launch
+int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
 {
     if (!e->data_set) return fail(MPPI_ESTATE, "solve before mppi_set_data");
-    e->last_stream = st;
     int rc = ensure_geometry(e);
     if (rc) return rc;
+    if (e->pending && (!carry || e->strict || e->pending_stream != st)) {
+        if ((rc = flush_pending(e))) return rc;
+    }
+    e->last_stream = st;
     if (e->injected && e->inj_dirty) {
         HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, e->C, e->nq, st));
         e->inj_dirty = false;
@@ -384,14 +461,33 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st)
             e->args_valid = true;
         }
     }
+    mppi::DeferredCombine dc;
+    memset(&dc, 0, sizeof dc);
+    if (e->pending) {       // same stream, fused kernel: the pending combine rides in this launch
+        mppi::CombineArgs ca;
+        fill_own_combine(e, ca, 0, 0);             // per-solve fields travel by value
+        if (!e->cargs_valid || memcmp(&ca, &e->h_cargs_last, sizeof ca) != 0) {
+            HIPCHK(hipMemcpyAsync(e->d_cargs, &ca, sizeof ca, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+            e->h_cargs_last = ca;
+            e->cargs_valid = true;
+        }
+        dc.args = e->d_cargs;
+        dc.solve_idx = e->pending_idx;
+        e->u_epoch += 1;
+        if (e->u_epoch == 0) e->u_epoch = 1;
+        dc.tag = e->u_epoch;
+        dc.n_blocks = ca.n_cols * ca.RS;
+        e->pending = false;
+    }
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
     mppi::LaunchTiming tm;
-    if ((rc = prof_pair(e, tm))) return rc;
+    if ((rc = prof_pair(e, tm, 0))) return rc;
     const bool sample_in_kernel = !e->injected && !pipelined;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
     else
-        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, sample_in_kernel, e->grid, ra, st, tm));
+        HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, sample_in_kernel, e->grid, ra, dc, st, tm));
     e->last_E = Ecur;
     e->last_C = e->C;
     e->last_nq = e->nq;
@@ -407,6 +503,7 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     if (n_parts < 1 || n_parts > mppi::kMaxParts)
         return fail(MPPI_EINVAL, "n_parts %d out of range", n_parts);
     mppi::CombineArgs ca;
+    memset(&ca, 0, sizeof ca);                 // (U_tag = null: only the small combine tags)
     ca.dev = e->d_state;
     ca.m = m; ca.s = s; ca.N = N;
     ca.m_stride = ms; ca.s_stride = ss; ca.N_stride = Ns;
@@ -432,8 +529,8 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
         ca.x.parity = (int)(e->xg_seq & 1ull);
         ca.x.tag = (unsigned int)(e->xg_seq % 0xFFFFFFFFull) + 1u;
         ca.x.timeout_ticks = (unsigned long long)(e->xg_timeout_s * 1e8);   // 100 MHz clock
-        ca.x.err_dev = e->d_xg_err;
-        ca.x.err_host = e->h_xg_err_dev;
+        ca.x.err_dev = e->d_err;
+        ca.x.err_host = e->h_err_dev;
     }
     {
         const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
@@ -441,7 +538,7 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     }
     mppi::LaunchTiming tm;
     {
-        int rc = prof_pair(e, tm);
+        int rc = prof_pair(e, tm, 1);
         if (rc) return rc;
     }
     if (prefetch_noise && e->pipeline && !e->injected && !e->strict && !getenv("MPPI_DEBUG_NOPREFETCH")) {
@@ -501,6 +598,17 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
         HIPCHK(hipMalloc(&e->d_tickets, nt * sizeof(unsigned int)));
         HIPCHK(hipMemset(e->d_tickets, 0, nt * sizeof(unsigned int)));
     }
+    HIPCHK(hipMalloc(&e->d_err, sizeof(int)));
+    HIPCHK(hipMemset(e->d_err, 0, sizeof(int)));
+    HIPCHK(hipHostMalloc(&e->h_err, sizeof(int), hipHostMallocMapped));
+    *e->h_err = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&e->h_err_dev, e->h_err, 0));
+    {
+        const size_t words = (size_t)(mppi::kMaxSmallSplits + 1) * e->TA;
+        HIPCHK(hipMalloc(&e->d_slab_tag, words * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(e->d_slab_tag, 0, words * sizeof(unsigned long long)));
+    }
+    HIPCHK(hipMalloc(&e->d_cargs, sizeof(mppi::CombineArgs)));
     HIPCHK(hipHostMalloc(&e->h_act, 4 * sizeof(float), hipHostMallocMapped));
     memset(e->h_act, 0, 4 * sizeof(float));
     HIPCHK(hipHostGetDevicePointer((void**)&e->h_act_dev, e->h_act, 0));
@@ -547,12 +655,17 @@ int mppi_create_shard(int nb_sim_local, long long k_offset, int steps, float dt,
 void mppi_destroy(mppi_engine* e)
 {
     if (!e) return;
+    e->pending = false;         // results nobody asked for
+    if (e->last_stream && e->last_stream != e->stream) (void)hipStreamSynchronize(e->last_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     (void)mppi_xchg_close(e);
     (void)hipFree(e->d_xg_peers);
-    (void)hipFree(e->d_xg_err);
-    if (e->h_xg_err) (void)hipHostFree(e->h_xg_err);
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    (void)hipFree(e->d_err);
+    if (e->h_err) (void)hipHostFree(e->h_err);
+    (void)hipFree(e->d_slab_tag);
+    (void)hipFree(e->d_cargs);
+    for (auto& list : e->ev)
+        for (hipEvent_t ev : list) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_state);
     (void)hipFree(e->d_U);
     (void)hipFree(e->d_Eint);
@@ -577,7 +690,10 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
                   const float* w)
 {
     if (!e || !x0 || !u || !goal || !w) return fail(MPPI_EINVAL, "null argument");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
     for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
     e->noise_ready_idx = -1;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
@@ -612,11 +728,20 @@ int mppi_solve_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    int rc = enqueue_rollout(e, st);
+    const bool defer = e->defer && !e->pipeline;
+    int rc = enqueue_rollout(e, st, defer);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr,
-                         true);
-    if (rc) return rc;
+    if (defer && !e->strict) {
+        // the combine is not launched yet: it rides at the front of the next solve's launch, or
+        // is flushed by the first call that needs this solve's results
+        e->pending = true;
+        e->pending_idx = e->solve_idx;
+        e->pending_stream = st;
+    } else {
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr,
+                             true);
+        if (rc) return rc;
+    }
     e->solve_idx += 1;
     e->have_solve = true;
     return MPPI_OK;
@@ -625,16 +750,21 @@ int mppi_solve_async(mppi_engine* e, void* stream)
 int mppi_sync_act(mppi_engine* e, float* next_act)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    if (e->last_stream && e->last_stream != e->stream)
-        HIPCHK(hipStreamSynchronize(e->last_stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc = settle(e);
+        if (rc) return rc;
+    }
     if (next_act)
         for (int i = 0; i < e->A; ++i) next_act[i] = e->h_act[i];
-    if (e->h_xg_err && *e->h_xg_err) {
-        *e->h_xg_err = 0;
-        (void)hipMemset(e->d_xg_err, 0, sizeof(int));
-        return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
-                    "solve %llu", e->xg_timeout_s, e->solve_idx);
+    if (e->h_err && *e->h_err) {
+        const int code = *e->h_err;
+        *e->h_err = 0;
+        (void)hipMemset(e->d_err, 0, sizeof(int));
+        if (code == 1)
+            return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
+                        "solve %llu", e->xg_timeout_s, e->solve_idx);
+        return fail(MPPI_ESTATE, "device watchdog %d: a rollout block waited 2 s for the combine "
+                    "riding in its own launch", code);
     }
     return MPPI_OK;
 }
@@ -650,7 +780,10 @@ int mppi_get_act(mppi_engine* e, float* next_act)
 int mppi_get_u(mppi_engine* e, float* u)
 {
     if (!e || !u) return fail(MPPI_EINVAL, "null argument");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
     HIPCHK(hipMemcpy(u, e->d_U + (e->solve_idx & 1ull) * e->TA, (size_t)e->TA * sizeof(float),
                      hipMemcpyDeviceToHost));
     return MPPI_OK;
@@ -660,7 +793,10 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
                  float* nabla, float* weight)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
     if ((x_all || noise || cost || beta || nabla || weight) && !e->have_solve)
         return fail(MPPI_ESTATE, "no solve has run since mppi_set_data");
     int rc;
@@ -677,7 +813,10 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         if ((rc = ensure_scratch(e, (size_t)e->K))) return rc;
         HIPCHK(mppi::launch_weights(e->d_cost, e->d_state, e->lambda, e->d_scratch, e->K,
                                     e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
         HIPCHK(hipMemcpy(weight, e->d_scratch, (size_t)e->K * sizeof(float),
                          hipMemcpyDeviceToHost));
     }
@@ -686,7 +825,10 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         if ((rc = ensure_scratch(e, n))) return rc;
         HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_C,
                                          e->last_nq, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
         HIPCHK(hipMemcpy(noise, e->d_scratch, n * sizeof(float), hipMemcpyDeviceToHost));
     }
     if (x_all) {
@@ -698,7 +840,10 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         HIPCHK(mppi::launch_trace_states(e->A, e->last_E, e->d_U + (e->last_idx & 1ull) * e->TA,
                                          d_x0, e->d_scratch, e->K, e->T, e->last_C, e->last_nq,
                                          e->dt, e->B0, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
         HIPCHK(hipMemcpy(x_all, e->d_scratch, n * sizeof(float), hipMemcpyDeviceToHost));
     }
     return MPPI_OK;
@@ -713,6 +858,10 @@ int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const floa
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!(lambda > 0.f)) return fail(MPPI_EINVAL, "lambda must be positive");
+    {   // a pending combine belongs to the old lambda
+        int rc_ = flush_pending(e);
+        if (rc_) return rc_;
+    }
     e->lambda = lambda;
     if (sigma) {
         for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
@@ -733,7 +882,10 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed)
 int mppi_set_noise(mppi_engine* e, const float* noise)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
     if (!noise) {
         e->injected = false;
         return MPPI_OK;
@@ -752,6 +904,10 @@ int mppi_set_ref_compat(mppi_engine* e, int on)
     if (on && e->A == 1)
         return fail(MPPI_EINVAL, "ref_compat for act_dim 1 is not implemented");
     if (on && e->sharded) return fail(MPPI_EINVAL, "ref_compat is single-GPU only");
+    {
+        int rc_ = flush_pending(e);
+        if (rc_) return rc_;
+    }
     e->ref_compat = on != 0;
     return MPPI_OK;
 }
@@ -760,7 +916,10 @@ int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (chunks < 0 || max_blocks < 0) return fail(MPPI_EINVAL, "negative tuning value");
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
     e->user_chunks = chunks;
     e->user_strict = strict;
     e->user_max_blocks = max_blocks;
@@ -773,8 +932,13 @@ int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks)
 int mppi_set_pipeline(mppi_engine* e, int on)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    HIPCHK(hipStreamSynchronize(e->stream));
-    e->pipeline = on ? 1 : 0;
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
+    if (on < 0 || on > 2) return fail(MPPI_EINVAL, "pipeline mode must be 0, 1 or 2");
+    e->pipeline = on == 1 ? 1 : 0;
+    e->defer = on == 0 ? 1 : 0;
     e->noise_ready_idx = -1;
     e->geom_ok = false;         // the occupancy-sized grid depends on the kernel variant
     return MPPI_OK;
@@ -786,7 +950,7 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
 {
     if (!e || !d_partial) return fail(MPPI_EINVAL, "null argument");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    int rc = enqueue_rollout(e, st);
+    int rc = enqueue_rollout(e, st);      // (flushes a pending combine first)
     if (rc) return rc;
     rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial,
                          true);
@@ -843,13 +1007,6 @@ int mppi_xchg_open(mppi_engine* e, int rank, int world, void* handle_out, void**
     HIPCHK(hipMemset(p, 0, bytes));
     HIPCHK(hipDeviceSynchronize());
     if (!e->d_xg_peers) HIPCHK(hipMalloc(&e->d_xg_peers, mppi::kMaxRanks * sizeof(void*)));
-    if (!e->d_xg_err) {
-        HIPCHK(hipMalloc(&e->d_xg_err, sizeof(int)));
-        HIPCHK(hipMemset(e->d_xg_err, 0, sizeof(int)));
-        HIPCHK(hipHostMalloc(&e->h_xg_err, sizeof(int), hipHostMallocMapped));
-        *e->h_xg_err = 0;
-        HIPCHK(hipHostGetDevicePointer((void**)&e->h_xg_err_dev, e->h_xg_err, 0));
-    }
     if (handle_out) {
         hipIpcMemHandle_t h;
         HIPCHK(hipIpcGetMemHandle(&h, p));
@@ -930,7 +1087,7 @@ int mppi_set_profiling(mppi_engine* e, int on)
     e->prof = on > 0 ? on : 0;
     e->prof_now = false;
     e->prof_count = 0;
-    e->ev_used = 0;
+    e->ev_used[0] = e->ev_used[1] = 0;
     return MPPI_OK;
 }
 
@@ -941,9 +1098,9 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out)
     HIPCHK(hipDeviceSynchronize());
     double tot = 0.0;
     int n = 0;
-    for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
+    for (size_t i = 0; i + 2 <= e->ev_used[which]; i += 2) {
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev[i + 2 * which], e->ev[i + 2 * which + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[which][i], e->ev[which][i + 1]));
         tot += ms;
         ++n;
     }

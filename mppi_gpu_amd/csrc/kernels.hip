@@ -23,6 +23,7 @@
 //
 // No MFMA: there is no dense contraction on this path. Bound: HBM (E store) / VALU (Philox).
 #include "device_common.hpp"
+#include "combine_impl.hpp"
 
 #include <cstring>
 
@@ -193,108 +194,8 @@ k_generate(const GenArgs g)
 }
 
 // ------------------------------------------------------------------------------------------
-// Combine: beta (src/point_mass.cu:273-322), nabla (:328-377), weighted update
-// (:384-480), action read-out and shift (:195-199, :805-824) in one launch.
-//
-// Grid = (ceil(TA/16) column blocks) x (RS row splits), 1024 threads.  Every block recomputes
-// beta and nabla from the (<= kMaxParts) partial minima / exp-sums in a fixed order, then sums
-// ITS rows of the weighted-noise partials for ITS 16 columns, all row loads in flight, four
-// rows per wave-instruction.  With RS > 1 the splits meet through a per-column-block ticket: each
-// stores its 64 sums, releases at agent scope and takes a ticket; the block that draws the
-// last ticket acquires and adds the RS slabs IN SPLIT ORDER (so the result does not depend on
-// arrival order) and applies the update.  The ticket is zero at creation and reset by the
-// last arriver.
+// Combine launches (the body lives in combine_impl.hpp).
 // ------------------------------------------------------------------------------------------
-// ---- rank-partial exchange words (XchgArgs) -------------------------------------------------
-__device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigned int tag)
-{
-    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Poll inbox word p1 (and p2 when non-null, both loads in flight together) until they carry
-// `tag`; bounded by the exchange time-out so that every wave reaches its exit whatever the
-// peers do.
-__device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const unsigned long long* p2,
-                                         unsigned int tag, unsigned long long limit, float& v1,
-                                         float& v2, int& timed_out)
-{
-    const unsigned long long t0 = wall_clock64();
-    bool ok1 = (p1 == nullptr), ok2 = (p2 == nullptr);
-    v1 = 0.0f;
-    v2 = 0.0f;
-    for (;;) {
-        unsigned long long w1 = 0, w2 = 0;
-        if (!ok1) w1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!ok2) w2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!ok1 && (unsigned int)(w1 >> 32) == tag) {
-            v1 = __uint_as_float((unsigned int)w1);
-            ok1 = true;
-        }
-        if (!ok2 && (unsigned int)(w2 >> 32) == tag) {
-            v2 = __uint_as_float((unsigned int)w2);
-            ok2 = true;
-        }
-        if (ok1 && ok2) return;
-        if (wall_clock64() - t0 > limit) {
-            timed_out = 1;
-            return;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-// Final combine of G rank partials held in LDS (xm[g], xs[g], xv[g][col]), rank order, one
-// thread per column; shared by the direct exchange and by the gathered (RCCL) path.
-__device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int tid, int G,
-                                               const float* xm, const float* xs, const float* xv,
-                                               float uin)
-{
-    if (tid >= kCombineCols) return;
-    const int n = cb * kCombineCols + tid;
-    float beta = xm[0];
-    for (int g = 1; g < G; ++g) beta = fminf(beta, xm[g]);
-    float nabla = 0.0f, tot = 0.0f;
-    for (int g = 0; g < G; ++g) {
-        const float r = (xm[g] < INFINITY) ? expf(-a.inv_lambda * (xm[g] - beta)) : 0.0f;
-        nabla = fmaf(r, xs[g], nabla);
-        tot = fmaf(r, xv[g * kCombineCols + tid], tot);
-    }
-    if (n < a.TA) {
-        float* Uout = a.U + ((a.solve_idx + 1ull) & 1ull) * a.TA;
-        const float unew = uin + tot / nabla;
-        if (n < a.A) {
-            a.act_dev[n] = unew;
-            if (a.act_host) a.act_host[n] = unew;
-        } else {
-            Uout[n - a.A] = unew;
-        }
-        if (n >= a.TA - a.A) Uout[n] = unew;   // last step repeated
-    }
-    if (cb == 0 && tid == 0) {
-        a.dev->beta = beta;
-        a.dev->nabla = nabla;
-    }
-}
-
-__device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float uin, float tot,
-                                              float nabla)
-{
-    if (a.final_mode) {
-        float* Uout = a.U + ((a.solve_idx + 1ull) & 1ull) * a.TA;
-        const float unew = uin + tot / nabla;
-        if (n < a.A) {
-            a.act_dev[n] = unew;
-            if (a.act_host) a.act_host[n] = unew;
-        } else {
-            Uout[n - a.A] = unew;
-        }
-        if (n >= a.TA - a.A) Uout[n] = unew;   // last step repeated
-    } else {
-        a.partial_out[2 + n] = tot;
-    }
-}
-
 template <int NR, int GA>    // NR row loads in flight per lane; GA = act_dim of the generation role, 0 = none
 __global__ void __launch_bounds__(kCombineThreads)
 k_combine(const CombineArgs a, const GenArgs gen)
@@ -309,186 +210,18 @@ k_combine(const CombineArgs a, const GenArgs gen)
             return;
         }
     }
-    __shared__ float r_lds[kMaxParts];
-    constexpr int RPW = 64 / kCombineCols;            // rows per wave-instruction
-    constexpr int NRG = 16 * RPW;                     // row groups per block
-    __shared__ float red[NRG * kCombineCols];
-    __shared__ float scal[32];
-    __shared__ int last_flag;
+    __shared__ float smem[combine_smem_floats<kCombineThreads>()];
+    combine_body<kCombineThreads, NR>(a, (int)blockIdx.x, carve_combine_smem<kCombineThreads>(smem));
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;   // 0..15
-    const int cb = (int)blockIdx.x % a.n_cols;
-    const int rs = (int)blockIdx.x / a.n_cols;
-    const int RS = a.RS;
-    constexpr int PT = kMaxParts / kCombineThreads;   // partials per thread
-
-    // rows of this split
-    const int per = (a.n_parts + RS - 1) / RS;
-    const int p_begin = rs * per;
-    const int p_end = min(a.n_parts, p_begin + per);
-    const int col = lane & (kCombineCols - 1);
-    const int rgrp = wave * RPW + lane / kCombineCols;   // 0..NRG-1
-    const int n = cb * kCombineCols + col;
-
-    // ---- every global load this block needs is issued up front: the partial minima and
-    //      exp-sums, the first batch of weighted-noise rows and the nominal control; beta,
-    //      nabla and the rescale factors are computed while they are in flight -------------
-    float mreg[PT], sreg[PT];
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int p = tid + j * kCombineThreads;
-        mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
-        sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
-    }
-    float v[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + NRG * j;
-        v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
-    }
-    float uin = 0.0f;
-    if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
-
-    float mloc = mreg[0];
-#pragma unroll
-    for (int j = 1; j < PT; ++j) mloc = fminf(mloc, mreg[j]);
-    mloc = wave_min(mloc);
-    if (lane == 0) scal[wave] = mloc;
-    __syncthreads();
-    float beta = scal[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) beta = fminf(beta, scal[i]);
-
-    float sloc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int p = tid + j * kCombineThreads;
-        const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
-        if (p < a.n_parts) r_lds[p] = r;
-        sloc += r * sreg[j];
-    }
-    sloc = wave_sum(sloc);
-    if (lane == 0) scal[16 + wave] = sloc;
-    __syncthreads();
-    float nabla = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) nabla += scal[16 + i];
-
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + NRG * j;
-        if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
-    }
-    if (n < a.TA) {      // rows beyond the first batch (only when RS hit its cap)
-        for (int p0 = p_begin + rgrp + NRG * NR; p0 < p_end; p0 += NRG * NR) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int p = p0 + NRG * j;
-                v[j] = (p < p_end) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const int p = p0 + NRG * j;
-                if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
-            }
-        }
-    }
-    red[rgrp * kCombineCols + col] = acc;
-    __syncthreads();
-    float tot = 0.0f;
-    if (wave == 0) {       // both halves of the wave compute the same 32 sums, in row-group order
-#pragma unroll
-        for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
-    }
-
-    // `mine`: this rank's finished sums for the block's 16 columns (threads 0..15 of the block
-    // that applies them); apply_blk is block-uniform
-    float mine = tot;
-    bool apply_blk = true;
-    if (RS > 1) {
-        // publish this split's 64 sums, then take a ticket (guide: agent-scope release before
-        // the counter, agent-scope acquire in the last arriver, waits written out by hand)
-        if (tid < kCombineCols && n < a.TA) a.slab[(size_t)rs * a.TA + n] = tot;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int old = __hip_atomic_fetch_add(&a.tickets[cb], 1u, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-            const int is_last = (old == (unsigned int)(RS - 1));
-            if (is_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&a.tickets[cb], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            last_flag = is_last;
-        }
-        __syncthreads();
-        apply_blk = last_flag != 0;
-        if (apply_blk && tid < kCombineCols && n < a.TA) {
-            float t2 = 0.0f;
-            for (int q = 0; q < RS; ++q)
-                t2 += __hip_atomic_load(&a.slab[(size_t)q * a.TA + n], __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
-            mine = t2;
-        }
-    }
-    if (a.final_mode != 2) {
-        if (apply_blk && tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, mine, nabla);
-        if (cb == 0 && rs == 0 && tid == 0) {
-            if (a.final_mode) {
-                a.dev->beta = beta;
-                a.dev->nabla = nabla;
-            } else {
-                a.partial_out[0] = beta;
-                a.partial_out[1] = nabla;
-            }
-        }
-        return;
-    }
-    if (!apply_blk) return;
-
-    // ---- direct exchange: send this rank's partial to every inbox, collect all G, finish ----
-    const XchgArgs& x = a.x;
-    float* xv = r_lds;                                   // [G][16]   (r_lds is free by now)
-    float* xm = r_lds + kMaxRanks * kCombineCols;        // [G]
-    float* xs = xm + kMaxRanks;                          // [G]
-    float* mine_lds = xs + kMaxRanks;                    // [16]
-    __syncthreads();
-    if (tid < kCombineCols) mine_lds[tid] = (n < a.TA) ? mine : 0.0f;
-    __syncthreads();
-    const int g = tid / kCombineCols;                    // peer this thread talks to
-    const int c = tid & (kCombineCols - 1);
-    const int nn = cb * kCombineCols + c;
-    const size_t slot_w = (size_t)x.W;
-    if (g < x.G) {
-        unsigned long long* dst = x.peers[g] + ((size_t)x.parity * x.G + x.rank) * slot_w;
-        if (nn < a.TA) ll_store(dst + 2 + nn, mine_lds[c], x.tag);
-        if (cb == 0 && c == 0) {
-            ll_store(dst + 0, beta, x.tag);
-            ll_store(dst + 1, nabla, x.tag);
-        }
-    }
-    int timed_out = 0;
-    if (g < x.G) {
-        const unsigned long long* src = x.peers[x.rank] + ((size_t)x.parity * x.G + g) * slot_w;
-        float v1, v2;   // column word of rank g; columns 0 / 1 also fetch beta_g / S_g
-        ll_poll2((nn < a.TA) ? src + 2 + nn : nullptr, (c < 2) ? src + c : nullptr, x.tag,
-                 x.timeout_ticks, v1, v2, timed_out);
-        xv[g * kCombineCols + c] = v1;
-        if (c == 0) xm[g] = v2;
-        if (c == 1) xs[g] = v2;
-    }
-    if (timed_out) {
-        *x.err_dev = 1;
-        if (x.err_host) *x.err_host = 1;
-    }
-    __syncthreads();
-    finish_columns(a, cb, tid, x.G, xm, xs, xv, uin);
+// The combine in the block shape of the fused rollout (256 threads): what a deferred combine that
+// found no next solve to ride with is flushed through -- same device function, same bits.
+__global__ void __launch_bounds__(kRolloutThreads)
+k_combine_small(const CombineArgs a)
+{
+    __shared__ float smem[combine_smem_floats<kRolloutThreads>()];
+    combine_body<kRolloutThreads, kSmallCombineNR>(a, (int)blockIdx.x,
+                                                   carve_combine_smem<kRolloutThreads>(smem));
 }
 
 // Final combine of G gathered rank partials (the collective-library transport): one block per 16
@@ -630,13 +363,12 @@ size_t rollout_lds_bytes(int NBTp, int TAp)
 }
 
 template <int A>
-hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a, hipStream_t st,
-                          LaunchTiming tm);
-extern template hipError_t launch_fused_a<1>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
-extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
-extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
-extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, hipStream_t, LaunchTiming);
-
+hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
+                          const DeferredCombine& d, hipStream_t st, LaunchTiming tm);
+extern template hipError_t launch_fused_a<1>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
+extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
 template <int A>
 int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds);
 extern template int fused_blocks_per_cu_a<1>(int, bool, size_t);
@@ -656,15 +388,38 @@ int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds)
 }
 
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
-                                hipStream_t st, LaunchTiming tm)
+                                const DeferredCombine& d, hipStream_t st, LaunchTiming tm)
 {
     switch (A) {
-        case 1: return launch_fused_a<1>(NGt, sample, grid, a, st, tm);
-        case 2: return launch_fused_a<2>(NGt, sample, grid, a, st, tm);
-        case 3: return launch_fused_a<3>(NGt, sample, grid, a, st, tm);
-        case 4: return launch_fused_a<4>(NGt, sample, grid, a, st, tm);
+        case 1: return launch_fused_a<1>(NGt, sample, grid, a, d, st, tm);
+        case 2: return launch_fused_a<2>(NGt, sample, grid, a, d, st, tm);
+        case 3: return launch_fused_a<3>(NGt, sample, grid, a, d, st, tm);
+        case 4: return launch_fused_a<4>(NGt, sample, grid, a, d, st, tm);
         default: return hipErrorInvalidValue;
     }
+}
+
+int combine_small_prepare(CombineArgs& a)
+{
+    constexpr int kRowGroups = (kRolloutThreads / 64) * (64 / kCombineCols);
+    const int cols = (a.TA + kCombineCols - 1) / kCombineCols;
+    // ~20 rows per lane and split (measured flat between 10 and 40, MI355X), at most
+    // kMaxSmallSplits splits
+    int rs = a.row_splits > 0 ? a.row_splits : (a.n_parts + kRowGroups * 20 - 1) / (kRowGroups * 20);
+    if (rs < 1) rs = 1;
+    if (rs > kMaxSmallSplits) rs = kMaxSmallSplits;
+    a.n_cols = cols;
+    a.RS = rs;
+    return cols * rs;
+}
+
+size_t combine_small_lds_bytes() { return combine_smem_floats<kRolloutThreads>() * sizeof(float); }
+
+hipError_t launch_combine_small(const CombineArgs& a, hipStream_t st, LaunchTiming tm)
+{
+    const dim3 grid(a.n_cols * a.RS), block(kRolloutThreads);
+    MPPI_LAUNCH(k_combine_small, grid, block, 0, st, tm, a);
+    return hipGetLastError();
 }
 
 template <int A>

@@ -63,6 +63,11 @@ struct RolloutArgs {
     float sigma[4];
     float inv_s[4];
     float x0[8];           // host copy of the current state (travels by value in RolloutHot)
+    // read only on the riding path (DeferredCombine), kept here so that they cost no kernel
+    // argument registers: the tagged finished controls and the device watchdog words
+    const unsigned long long* fin_tag;
+    int* err_dev;
+    int* err_host;
 };
 
 // What the first instructions of the fused rollout need, passed BY VALUE as kernel arguments
@@ -83,9 +88,10 @@ struct RolloutHot {
 };
 #ifdef MPPI_TRACE
 extern unsigned long long* g_mppi_trace_buf;     // [kMaxParts][16], engine.hip
+#define MPPI_TRACE_PTR(h) ((h).trace)
 #define MPPI_STAMP(i)                                                                    \
     do {                                                                                 \
-        if (h.trace && threadIdx.x == 0) h.trace[(size_t)blockIdx.x * 16 + (i)] = clock64(); \
+        if (h.trace && threadIdx.x == 0) h.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
 #else
 #define MPPI_STAMP(i) do { } while (0)
@@ -148,6 +154,12 @@ struct CombineArgs {
     // partial mode: out[0]=beta_g, out[1]=S_g, out[2..2+TA)=N_g
     float* partial_out;
     float* slab;           // [kMaxRowSplits][TA] row-split sums (RS > 1)
+    // 256-thread shape only (else null): the row splits' sums as TAGGED 8-byte words
+    // {float bits, tag}, [kMaxSmallSplits][TA], then the finished values unew[n] (before the
+    // shift) [TA] -- old or complete, never torn, so neither the split meeting nor a rollout
+    // riding in the same launch needs a fence
+    unsigned long long* slab_tag;
+    unsigned int tag;               // this combine's tag: the engine's combine count, never reused
     unsigned int* tickets; // [ceil(TA/64)] arrival counters, zero between launches
     unsigned long long solve_idx;
     int final_mode;        // 0 partial -> partial_out, 1 final, 2 partial -> peer exchange -> final
@@ -156,12 +168,32 @@ struct CombineArgs {
     int n_cols, RS;        // filled by the launcher: column blocks and row splits of the grid
 };
 
+// A combine that rides at the front of the NEXT solve's rollout launch (mppi_solve_async back to
+// back): the first n_blocks blocks of the grid play the combine role for solve `solve_idx` while
+// the rollout blocks draw their noise, which does not depend on the controls.  A rollout block
+// then takes the new controls from the TAGGED words the applying combine blocks publish (value
+// n of the update, before the shift: U[i] = unew[i + A], the last step repeats), polling any word
+// whose tag is not yet this combine's (bounded).  No fence and no counter is involved, so the
+// megabytes of noise the rollout blocks leave dirty in the L2s are never written back for the
+// hand-over (measured: agent-scope release/acquire fences here cost 4 us per launch).  Blocks are
+// dispatched in index order: the combine blocks hold their slots before any rollout block can
+// wait for them.  (Letting the rollout blocks add the row splits' sums themselves saves a hop but
+// multiplies the polled words by RS + 2: measured slower, 17.4 vs 17.0 us at C2.)
+struct DeferredCombine {
+    const CombineArgs* args;          // device copy; solve_idx and tag are taken from here instead
+    unsigned long long solve_idx;
+    unsigned int tag;
+    int n_blocks;                     // 0 = nothing rides with this launch
+};
+
 constexpr int kRolloutThreads = 256;
 constexpr int kCombineThreads = 1024;
 constexpr int kCombineCols = 16;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
-constexpr int kMaxRanks = kCombineThreads / kCombineCols;   // one combine thread per (rank, column)
+constexpr int kMaxRanks = 64;     // rank partials one combine block can hold (LDS xv[][16])
+constexpr int kSmallCombineNR = 24;   // up to 384 rows per split
+constexpr int kMaxSmallSplits = 8;    // row splits of the 256-thread combine (one poll batch)   // row loads in flight per lane of the 256-thread combine
 constexpr int kParamFloats = 32;   // LDS floats holding the problem constants in the fused rollout
 
 // Group geometry by action dimension and the instantiated register-resident chunk lengths
@@ -181,8 +213,16 @@ struct LaunchTiming {
     hipEvent_t stop = nullptr;
 };
 
+// grid = rollout blocks; d.n_blocks combine-role blocks are launched in front of them
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
-                                hipStream_t st, LaunchTiming tm = LaunchTiming());
+                                const DeferredCombine& d, hipStream_t st,
+                                LaunchTiming tm = LaunchTiming());
+// The combine in 256-thread blocks (what rides in the rollout launch, and what flushes a deferred
+// combine that found no next solve): fills a.n_cols / a.RS, returns the number of blocks.
+int combine_small_prepare(CombineArgs& a);
+size_t combine_small_lds_bytes();
+hipError_t launch_combine_small(const CombineArgs& a_prepared, hipStream_t st,
+                                LaunchTiming tm = LaunchTiming());
 // Noise generation outside the rollout (pipelined mode): fills one tile-layout buffer with the
 // noise of one solve; identical values to what the fused kernel draws in place.
 struct GenArgs {

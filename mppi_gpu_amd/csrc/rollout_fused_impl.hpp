@@ -3,6 +3,7 @@
 // compile in parallel.
 #pragma once
 #include "device_common.hpp"
+#include "combine_impl.hpp"
 
 namespace mppi {
 
@@ -34,9 +35,14 @@ __device__ __forceinline__ float to_vgpr(float x)
     return x;
 }
 
-template <int A, int NG, bool SAMPLE, int LOGC>
-__device__ __forceinline__ void fused_body(const RolloutHot& h)
+template <int A, int NG, bool SAMPLE, int LOGC, bool RIDE>
+__device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCombine& d)
 {
+    // RIDE: d.n_blocks combine-role blocks come first in the grid, the rollout blocks follow and
+    // the controls are not final yet at kernel entry
+    const int bid = RIDE ? (int)blockIdx.x - d.n_blocks : (int)blockIdx.x;
+    const int nblk = RIDE ? (int)gridDim.x - d.n_blocks : (int)gridDim.x;
+    constexpr bool deferred = RIDE;
     constexpr int SG = Dim<A>::SG;
     constexpr int BPG = Dim<A>::BPG;
     constexpr int NE = NG * BPG * 4;          // normals held per lane
@@ -67,7 +73,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
     // ---- issue the loads of the nominal controls and of the cold constants; they complete
     //      while the first tile's Philox blocks are computed ----------------------------------
     const float lambda = g.lambda, inv_lambda = g.inv_lambda;
-    {
+    auto stage_controls_lds = [&]() {
         const float* Uin = h.U_in;
         for (int b = threadIdx.x; b < NBTp; b += kRolloutThreads) {
             float u[4], uc[4];
@@ -80,7 +86,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             ulds[b] = make_float4(u[0], u[1], u[2], u[3]);
             uclds[b] = make_float4(uc[0], uc[1], uc[2], uc[3]);
         }
-    }
+    };
+    if constexpr (!deferred) stage_controls_lds();
     LaneParams<A> P;
     float x0p[A], x0v[A];
 #pragma unroll
@@ -107,7 +114,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
     RunState rs{INFINITY, 0.0f};
     bool first = true;
 
-    for (int tb = blockIdx.x; tb < n_tileblk; tb += gridDim.x) {
+    for (int tb = bid; tb < n_tileblk; tb += nblk) {
         const long long gid = (long long)tb * kRolloutThreads + threadIdx.x;
         const long long kloc = gid >> LOGC;
         const bool valid = kloc < K;
@@ -149,7 +156,43 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
             }
         }
         if (first) MPPI_STAMP(1);
-        if (first) __syncthreads();      // U and lambda*inv_s*U are in LDS from here on
+        if (first) {
+            if constexpr (deferred) {
+                // The combine-role blocks of this very launch are producing this solve's
+                // controls: take them from the tagged words the applying blocks publish (see
+                // DeferredCombine), one value per thread and sweep, polling what is not there
+                // yet (bounded).
+                const unsigned long long t0 = wall_clock64();
+                const unsigned long long limit = 200000000ull;        // 2 s at 100 MHz
+                bool timed_out = false;
+                float* uflat = reinterpret_cast<float*>(ulds);
+                float* ucflat = reinterpret_cast<float*>(uclds);
+                const unsigned long long* fin_p = g.fin_tag;
+                for (int idx = threadIdx.x; idx < NBTp * 4; idx += kRolloutThreads) {
+                    float unew = 0.0f;
+                    if (idx < TA) {
+                        const int n = (idx < TA - A) ? idx + A : idx;  // shift; last step repeats
+                        for (;;) {
+                            const unsigned long long w = __hip_atomic_load(
+                                fin_p + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned int)(w >> 32) == d.tag) {
+                                unew = __uint_as_float((unsigned int)w);
+                                break;
+                            }
+                            if (wall_clock64() - t0 > limit) { timed_out = true; break; }
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    uflat[idx] = unew;
+                    ucflat[idx] = lambda * (unew * g.inv_s[idx % A]);
+                }
+                if (timed_out) {     // device watchdog word, reported by the next mppi_sync_act
+                    *g.err_dev = 2;
+                    if (g.err_host) *g.err_host = 2;
+                }
+            }
+            __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
+        }
         if (first) MPPI_STAMP(2);
 
         // ---- pass 1b: the chunk's zero-state response is two weighted sums of a = u + e:
@@ -347,11 +390,11 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h)
     MPPI_STAMP(9);
 
     // ---- publish the block partial ----------------------------------------------------------
-    float* Nout = g.part_N + (size_t)blockIdx.x * TA;
+    float* Nout = g.part_N + (size_t)bid * TA;
     for (int n = threadIdx.x; n < TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
     if (threadIdx.x == 0) {
-        g.part_m[blockIdx.x] = rs.M;
-        g.part_s[blockIdx.x] = rs.S;
+        g.part_m[bid] = rs.M;
+        g.part_s[bid] = rs.S;
     }
     MPPI_STAMP(10);
 }
@@ -366,37 +409,73 @@ constexpr int fused_min_waves()
     return NE <= 16 ? 4 : 2;
 }
 
+template <int A, int NG, bool SAMPLE, bool RIDE>
+__device__ __forceinline__ void fused_kernel_body(const RolloutHot& h, const DeferredCombine& d)
+{
+    if constexpr (RIDE) {
+        if ((int)blockIdx.x < d.n_blocks) {
+            // combine role: the previous solve's beta / nabla / update / shift (combine_impl.hpp)
+            // (the rollout blocks of this launch will wait for these few waves: let them win the
+            //  instruction arbitration against the Philox work sharing their SIMDs)
+            __builtin_amdgcn_s_setprio(3);
+            MPPI_STAMP(0);
+            extern __shared__ __align__(16) unsigned char smem_raw[];
+            CombineArgs a = *d.args;
+            a.solve_idx = d.solve_idx;
+            a.tag = d.tag;
+            combine_body<kRolloutThreads, kSmallCombineNR>(
+                a, (int)blockIdx.x,
+                carve_combine_smem<kRolloutThreads>(reinterpret_cast<float*>(smem_raw)));
+            MPPI_STAMP(10);
+            return;
+        }
+    }
+#ifdef MPPI_ONLY_LOGC          // analysis builds: a single body, for reading the ISA
+    fused_body<A, NG, SAMPLE, MPPI_ONLY_LOGC, RIDE>(h, d);
+    return;
+#endif
+    switch (h.logC) {      // wave-uniform: one specialised body per lanes-per-trajectory
+        case 0: fused_body<A, NG, SAMPLE, 0, RIDE>(h, d); break;
+        case 1: fused_body<A, NG, SAMPLE, 1, RIDE>(h, d); break;
+        case 2: fused_body<A, NG, SAMPLE, 2, RIDE>(h, d); break;
+        case 3: fused_body<A, NG, SAMPLE, 3, RIDE>(h, d); break;
+        case 4: fused_body<A, NG, SAMPLE, 4, RIDE>(h, d); break;
+        case 5: fused_body<A, NG, SAMPLE, 5, RIDE>(h, d); break;
+        default: fused_body<A, NG, SAMPLE, 6, RIDE>(h, d); break;
+    }
+}
+
 template <int A, int NG, bool SAMPLE>
 __global__ void __launch_bounds__(kRolloutThreads, (fused_min_waves<A, NG>()))
 k_rollout_fused(const RolloutHot h)
 {
-#ifdef MPPI_ONLY_LOGC          // analysis builds: a single body, for reading the ISA
-    fused_body<A, NG, SAMPLE, MPPI_ONLY_LOGC>(h);
-    return;
-#endif
-    switch (h.logC) {      // wave-uniform: one specialised body per lanes-per-trajectory
-        case 0: fused_body<A, NG, SAMPLE, 0>(h); break;
-        case 1: fused_body<A, NG, SAMPLE, 1>(h); break;
-        case 2: fused_body<A, NG, SAMPLE, 2>(h); break;
-        case 3: fused_body<A, NG, SAMPLE, 3>(h); break;
-        case 4: fused_body<A, NG, SAMPLE, 4>(h); break;
-        case 5: fused_body<A, NG, SAMPLE, 5>(h); break;
-        default: fused_body<A, NG, SAMPLE, 6>(h); break;
-    }
+    fused_kernel_body<A, NG, SAMPLE, false>(h, DeferredCombine());
+}
+
+// The same rollout with the previous solve's combine riding at the front of the grid
+// (DeferredCombine); a separate instantiation so that the plain kernel pays nothing for it.
+template <int A, int NG, bool SAMPLE>
+__global__ void __launch_bounds__(kRolloutThreads, (fused_min_waves<A, NG>()))
+k_rollout_ride(const RolloutHot h, const DeferredCombine d)
+{
+    fused_kernel_body<A, NG, SAMPLE, true>(h, d);
 }
 
 template <int A, int NG>
-hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, hipStream_t st,
-                          LaunchTiming tm)
+hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, const DeferredCombine& d,
+                          hipStream_t st, LaunchTiming tm)
 {
-    const size_t lds = rollout_lds_bytes(a.NBTp, a.C * a.nq * 4);
+    size_t lds = rollout_lds_bytes(a.NBTp, a.C * a.nq * 4);
+    if (d.n_blocks > 0 && lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
     const RolloutHot h = make_hot(a);
-    if (sample)
-        MPPI_LAUNCH((k_rollout_fused<A, NG, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
-                    h);
-    else
-        MPPI_LAUNCH((k_rollout_fused<A, NG, false>), dim3(grid), dim3(kRolloutThreads), lds, st,
-                    tm, h);
+    const dim3 g(grid + d.n_blocks), b(kRolloutThreads);
+    if (d.n_blocks > 0) {
+        if (sample) MPPI_LAUNCH((k_rollout_ride<A, NG, true>), g, b, lds, st, tm, h, d);
+        else MPPI_LAUNCH((k_rollout_ride<A, NG, false>), g, b, lds, st, tm, h, d);
+    } else {
+        if (sample) MPPI_LAUNCH((k_rollout_fused<A, NG, true>), g, b, lds, st, tm, h);
+        else MPPI_LAUNCH((k_rollout_fused<A, NG, false>), g, b, lds, st, tm, h);
+    }
     return hipGetLastError();
 }
 
@@ -440,24 +519,24 @@ int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds)
 
 template <int A>
 hipError_t launch_fused_a(int NGt, bool sample, int grid, const RolloutArgs& a,
-                          hipStream_t st, LaunchTiming tm)
+                          const DeferredCombine& d, hipStream_t st, LaunchTiming tm)
 {
     if constexpr (A == 3) {
         switch (NGt) {
-            case 1: return launch_fused_t<A, 1>(sample, grid, a, st, tm);
-            case 2: return launch_fused_t<A, 2>(sample, grid, a, st, tm);
-            case 4: return launch_fused_t<A, 4>(sample, grid, a, st, tm);
-            case 7: return launch_fused_t<A, 7>(sample, grid, a, st, tm);
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, d, st, tm);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, d, st, tm);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, d, st, tm);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, d, st, tm);
             default: return hipErrorInvalidValue;
         }
     } else {
         switch (NGt) {
-            case 1: return launch_fused_t<A, 1>(sample, grid, a, st, tm);
-            case 2: return launch_fused_t<A, 2>(sample, grid, a, st, tm);
-            case 4: return launch_fused_t<A, 4>(sample, grid, a, st, tm);
-            case 7: return launch_fused_t<A, 7>(sample, grid, a, st, tm);
-            case 13: return launch_fused_t<A, 13>(sample, grid, a, st, tm);
-            case 20: return launch_fused_t<A, 20>(sample, grid, a, st, tm);
+            case 1: return launch_fused_t<A, 1>(sample, grid, a, d, st, tm);
+            case 2: return launch_fused_t<A, 2>(sample, grid, a, d, st, tm);
+            case 4: return launch_fused_t<A, 4>(sample, grid, a, d, st, tm);
+            case 7: return launch_fused_t<A, 7>(sample, grid, a, d, st, tm);
+            case 13: return launch_fused_t<A, 13>(sample, grid, a, d, st, tm);
+            case 20: return launch_fused_t<A, 20>(sample, grid, a, d, st, tm);
             default: return hipErrorInvalidValue;
         }
     }

@@ -196,32 +196,120 @@ def test_closed_loop_sequence_matches_oracle_chain(gpu):
             assert np.array_equal(m.get_x(), x)
 
 
-def test_pipelined_noise_mode_is_equivalent(gpu):
-    """set_pipeline(True): the noise of solve j+1 is drawn inside solve j's combine launch into a
-    second buffer and the rollout reads it.  Same stream definition, so noise, costs and controls
-    must equal the in-place sampling mode bit for bit, solve after solve, also across set_x."""
-    A, K, T = 3, 3000, 50
-    c = ol.make_case(A, K, T, seed=123)
-    runs = []
-    for pipe in (False, True):
-        with _model(gpu, A, K, T, c) as m:
-            m.set_pipeline(pipe)
-            m.set_seed(77)
-            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
-            out = []
-            x = c["x0"].copy()
-            for it in range(4):
+def _run_mode(gpu, mode, A, K, T, c, blocking, n=5):
+    """n solves in pipeline `mode`; blocking = get_act + get_inf + set_x per solve (closed loop),
+    else the solves are enqueued back to back and only the end state is read."""
+    with _model(gpu, A, K, T, c) as m:
+        m.set_pipeline(mode)
+        m.set_seed(77)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        out = []
+        x = c["x0"].copy()
+        for it in range(n):
+            if blocking:
                 act = m.get_act()
                 inf = m.get_inf(x=False)
                 out.append((act, inf["e"], inf["cost"], inf["u"]))
                 x = (x + np.float32(0.01)).astype(np.float32)
                 m.set_x(x)
-            runs.append(out)
+            else:
+                m.solve_async()
+        if not blocking:
+            act = m.sync_act()
+            inf = m.get_inf(x=False)
+            out.append((act, inf["e"], inf["cost"], inf["u"], inf["beta"], inf["nabla"]))
+        return out
+
+
+def test_pipelined_noise_mode_is_equivalent(gpu):
+    """Mode 1: the noise of solve j+1 is drawn inside solve j's combine launch into a second buffer
+    and the rollout reads it.  Same stream definition, so noise, costs and controls must equal
+    the eager mode (2) bit for bit, solve after solve, also across set_x."""
+    A, K, T = 3, 3000, 50
+    c = ol.make_case(A, K, T, seed=123)
+    runs = [_run_mode(gpu, mode, A, K, T, c, True, n=4) for mode in (2, 1)]
     for it in range(4):
         for a, b in zip(runs[0][it], runs[1][it]):
             assert np.array_equal(a, b), f"pipelined mode differs at solve {it}"
-    # and against the oracle on the noise of the last solve
     assert not np.array_equal(runs[1][0][1], runs[1][1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A,K,T", [(2, 10000, 200), (3, 3000, 50), (1, 700, 33), (3, 40000, 120)])
+def test_deferred_combine_rides_and_flushes_with_equal_bits(gpu, A, K, T):
+    """Mode 0 (default): back-to-back mppi_solve_async calls carry the previous solve's combine in
+    the next rollout launch (rollout blocks wait on the agent-scope counter for the new controls);
+    get_act flushes it stand-alone.  Both are the same device function: a closed-loop chain of
+    get_act calls and a chain of asynchronous solves must end in identical bits.  Against the
+    eager mode (1024-thread combine, another summation order) the controls agree to rounding."""
+    c = ol.make_case(A, K, T, seed=124)
+    n = 6
+
+    def chain(mode, blocking):
+        with _model(gpu, A, K, T, c) as m:
+            m.set_pipeline(mode)
+            m.set_seed(78)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            acts = []
+            for it in range(n):
+                if blocking:
+                    acts.append(m.get_act())
+                else:
+                    m.solve_async()
+            if not blocking:
+                acts.append(m.sync_act())
+            inf = m.get_inf(x=False)
+            return acts[-1], inf["u"], inf["cost"], inf["e"], inf["beta"], inf["nabla"]
+
+    ride = chain(0, False)
+    flush = chain(0, True)
+    eager = chain(2, False)
+    for a, b in zip(ride, flush):
+        assert np.array_equal(a, b), "riding and flushed combine must give equal bits"
+    # another summation order: one solve's controls move by a few ulp(cost)/lambda relative weight
+    # change (module docstring); the chain of n solves feeds that back n times
+    scale = max(float(np.abs(eager[1]).max()), SIGMA)
+    cmax = float(np.abs(eager[2]).max())
+    bar = n * max(1e-5 * scale, 4 * float(np.spacing(np.float32(cmax))) * 4.5 * SIGMA)
+    assert np.abs(ride[1] - eager[1]).max() <= bar
+    assert np.abs(ride[0] - eager[0]).max() <= bar
+    assert abs(float(ride[4]) - float(eager[4])) <= 1e-5 * abs(float(eager[4]))
+
+
+@pytest.mark.gpu
+def test_deferred_combine_interleaved_with_everything_else(gpu):
+    """A pending combine must be flushed by every call that reads or changes what it touches:
+    set_x between asynchronous solves (rides on), get_u / get_inf / set_params / set_tuning /
+    set_data in the middle (flush), persistent grids with several tiles per block."""
+    A, K, T = 2, 9000, 60
+    c = ol.make_case(A, K, T, seed=125)
+
+    def script(mode):
+        with _model(gpu, A, K, T, c, max_blocks=24) as m:
+            m.set_pipeline(mode)
+            m.set_seed(5)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            log = []
+            m.solve_async(); m.solve_async()
+            m.set_x((c["x0"] * 0.9).astype(np.float32))
+            m.solve_async()
+            log.append(m.get_u())                       # flush
+            m.solve_async()
+            m.set_params(2.0, None, None)               # flush, new lambda for the next solve
+            m.solve_async(); m.solve_async()
+            log.append(m.sync_act())
+            m.set_tuning(chunks=8, strict=False, max_blocks=0)   # flush, new geometry
+            m.solve_async(); m.solve_async()
+            log.append(m.get_inf(x=False)["u"])
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.solve_async()
+            log.append(m.get_act())
+            return log
+
+    a, b = script(0), script(2)
+    for x, y in zip(a, b):
+        scale = max(float(np.abs(y).max()), SIGMA)
+        assert np.abs(x - y).max() <= 1e-4 * scale      # chains of up to 9 solves, see above
 
 
 def test_persistent_grid_and_rescale_path(gpu):

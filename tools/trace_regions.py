@@ -3,7 +3,7 @@
 OUT=../lib/trace/libmppi_gpu_amd.so OBJDIR=../lib/trace/obj; run with
 MPPI_GPU_AMD_LIB=mppi_gpu_amd/lib/trace/libmppi_gpu_amd.so).  Prints, over the blocks of one
 launch, when each region boundary is reached relative to the earliest block start (s_memtime
-ticks, 100 MHz on gfx950 -> 10 ns)."""
+ticks of the 100 MHz wall clock -> 10 ns)."""
 import ctypes as C
 import os
 import sys
@@ -28,9 +28,28 @@ for _ in range(50):
 m.sync_act()
 geo = m.geometry()
 grid = geo["grid"]
-buf = np.zeros((grid, 16), np.uint64)
-m.solve_async(); m.sync_act()
-assert lib.mppi_debug_trace(buf.ctypes.data, grid) == 0
+ride = int(os.environ.get("TRACE_RIDE", "0"))       # 1: trace a launch that carries a combine
+nb = 0
+if ride:
+    for _ in range(4):
+        m.solve_async()                              # the last launch carried a combine
+    m.sync_act()
+    import math
+    rs = max(1, math.ceil(grid / 160))
+    nb = math.ceil(T * A / 16) * rs
+else:
+    m.solve_async(); m.sync_act()
+buf = np.zeros((grid + nb, 16), np.uint64)
+assert lib.mppi_debug_trace(buf.ctypes.data, grid + nb) == 0
+if nb:
+    tc = buf[:nb].astype(np.int64)
+    t00 = min(tc[:, 0].min(), buf[nb:, 0].astype(np.int64).min())
+    print("combine-role blocks:", nb, " start (10 ns ticks after first block) p50/max",
+          np.median(tc[:, 0] - t00), (tc[:, 0] - t00).max(), " end p50/max",
+          np.median(tc[:, 10] - t00), (tc[:, 10] - t00).max())
+    buf = buf[nb:]
+    print("rollout blocks start p50/max", np.median(buf[:, 0].astype(np.int64) - t00),
+          (buf[:, 0].astype(np.int64) - t00).max(), " end max", (buf[:, 10].astype(np.int64) - t00).max())
 t = buf.astype(np.int64)
 d = t[:, :11] - t[:, :1]          # per block: ticks since its own entry (counters differ per XCD)
 names = ["entry", "pass1a done", "barrier 1", "1b+scan", "pass2", "min+exp", "nreduce", "barrier 2",
