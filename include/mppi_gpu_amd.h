@@ -127,6 +127,12 @@ int mppi_set_pipeline(mppi_engine* e, int mode);
  * mppi_sync_act.  Solves on one engine are ordered on the stream. */
 int mppi_solve_async(mppi_engine* e, void* stream);
 
+/* Launch whatever this engine still holds back (pipeline mode 0 defers the combine of the last
+ * enqueued solve until it knows what follows) without waiting for it.  Needed only by a host
+ * thread that drives SEVERAL engines exchanging with each other: flush all of them before waiting
+ * on the first, since a deferred exchange waits for the peers' words. */
+int mppi_flush_async(mppi_engine* e);
+
 /* Wait for everything enqueued by this engine and copy the last action into next_act[A]. */
 int mppi_sync_act(mppi_engine* e, float* next_act);
 
@@ -151,7 +157,9 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
  * mppi_solve_exchange_async, enqueues the rollout and ONE combine launch that stores this rank's
  * [beta_g, S_g, N_g[T*A]] into all inboxes as 8-byte {value, sequence tag} words over xGMI,
  * polls its own inbox for the other ranks' words and applies the update -- bit-identical to
- * mppi_solve_local_async + all-gather + mppi_solve_finish_async.  All ranks must make the same
+ * mppi_solve_local_async + all-gather + mppi_solve_finish_async.  In pipeline mode 0 that launch
+ * is deferred like the single-GPU combine: with solves enqueued back to back it rides in the next
+ * solve's rollout launch, and the peers' words arrive while this rank draws the next noise.  All ranks must make the same
  * sequence of exchange calls; a rank that waits longer than the time-out (default 5 s) gives up,
  * and the next mppi_sync_act / mppi_get_act returns MPPI_ESTATE.  world <= 64. */
 int mppi_xchg_handle_bytes(void);

@@ -175,6 +175,9 @@ class PointMassModel:
     def solve_async(self, stream=None):
         check(self._lib.mppi_solve_async(self._h, C.c_void_p(stream or 0)))
 
+    def flush_async(self):
+        check(self._lib.mppi_flush_async(self._h))
+
     def sync_act(self):
         act = np.empty(self.A, np.float32)
         check(self._lib.mppi_sync_act(self._h, _fp(act)))

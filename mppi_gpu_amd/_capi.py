@@ -38,6 +38,7 @@ SIGNATURES = {
     "mppi_set_tuning": (C.c_int, [engine_p, C.c_int, C.c_int, C.c_int]),
     "mppi_set_pipeline": (C.c_int, [engine_p, C.c_int]),
     "mppi_solve_async": (C.c_int, [engine_p, C.c_void_p]),
+    "mppi_flush_async": (C.c_int, [engine_p]),
     "mppi_sync_act": (C.c_int, [engine_p, c_float_p]),
     "mppi_partial_len": (C.c_int, [engine_p]),
     "mppi_solve_local_async": (C.c_int, [engine_p, C.c_void_p, C.c_void_p]),

@@ -117,7 +117,11 @@ __device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int
         nabla = fmaf(r, xs[g], nabla);
         tot = fmaf(r, xv[g * kCombineCols + tid], tot);
     }
-    if (n < a.TA) publish_control(a, n, updated_control(uin, tot, nabla));
+    if (n < a.TA) {
+        const float unew = updated_control(uin, tot, nabla);
+        publish_control(a, n, unew);
+        if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+    }
     if (cb == 0 && tid == 0) {
         a.dev->beta = beta;
         a.dev->nabla = nabla;

@@ -146,6 +146,8 @@ struct mppi_engine {
     // flushed by whatever needs its results
     int defer = 1;                          // 0 = every solve launches its own combine
     bool pending = false;
+    int pending_mode = 1;                   // 1 = final combine, 2 = peer exchange + final
+    unsigned long long pending_xseq = 0;    // exchange sequence number of a pending mode-2 combine
     unsigned long long pending_idx = 0;     // solve index of the pending combine
     hipStream_t pending_stream = nullptr;
     unsigned long long* d_slab_tag = nullptr;   // [kMaxSmallSplits][TA] tagged split sums + nabla
@@ -364,8 +366,11 @@ void fill_gen_args(const mppi_engine_t* e, mppi::GenArgs& ga, unsigned long long
 
 // the final combine of solve `idx` over this engine's own block partials, in the 256-thread shape
 // that rides in a rollout launch or is flushed stand-alone
+// mode: 0 rank partial -> partial_out, 1 final, 2 rank partial -> peer exchange (sequence number
+// xseq) -> final
 void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long long idx,
-                      unsigned int tag)
+                      unsigned int tag, int mode = 1, unsigned long long xseq = 0,
+                      float* partial_out = nullptr, bool per_solve_fields = true)
 {
     memset(&ca, 0, sizeof ca);
     ca.dev = e->d_state;
@@ -383,10 +388,22 @@ void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned lo
     ca.slab_tag = e->d_slab_tag;
     ca.tickets = e->d_tickets;
     ca.solve_idx = idx;
-    ca.final_mode = 1;
+    ca.final_mode = mode;
+    ca.partial_out = partial_out;
     ca.x.timeout_ticks = 200000000ull;         // 2 s: bound on the split meeting's polls
     ca.x.err_dev = e->d_err;
     ca.x.err_host = e->h_err_dev;
+    if (mode == 2) {
+        ca.x.peers = e->d_xg_peers;
+        ca.x.G = e->xg_world;
+        ca.x.rank = e->xg_rank;
+        ca.x.W = e->xg_W;
+        ca.x.timeout_ticks = (unsigned long long)(e->xg_timeout_s * 1e8);   // 100 MHz clock
+        if (per_solve_fields) {
+            ca.x.parity = (int)(xseq & 1ull);
+            ca.x.tag = (unsigned int)(xseq % 0xFFFFFFFFull) + 1u;
+        }
+    }
     const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
     ca.row_splits = env ? atoi(env) : 0;
     (void)mppi::combine_small_prepare(ca);
@@ -399,7 +416,7 @@ int flush_pending(mppi_engine_t* e)
     mppi::CombineArgs ca;
     e->u_epoch += 1;
     if (e->u_epoch == 0) e->u_epoch = 1;       // 0 is the tag of the zero-initialised buffer
-    fill_own_combine(e, ca, e->pending_idx, e->u_epoch);
+    fill_own_combine(e, ca, e->pending_idx, e->u_epoch, e->pending_mode, e->pending_xseq);
     mppi::LaunchTiming tm;
     int rc = prof_pair(e, tm, 1);
     if (rc) return rc;
@@ -465,7 +482,8 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     memset(&dc, 0, sizeof dc);
     if (e->pending) {       // same stream, fused kernel: the pending combine rides in this launch
         mppi::CombineArgs ca;
-        fill_own_combine(e, ca, 0, 0);             // per-solve fields travel by value
+        // per-solve fields (solve index, tags, exchange parity) travel by value
+        fill_own_combine(e, ca, 0, 0, e->pending_mode, 0, nullptr, false);
         if (!e->cargs_valid || memcmp(&ca, &e->h_cargs_last, sizeof ca) != 0) {
             HIPCHK(hipMemcpyAsync(e->d_cargs, &ca, sizeof ca, hipMemcpyHostToDevice, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -477,6 +495,8 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         e->u_epoch += 1;
         if (e->u_epoch == 0) e->u_epoch = 1;
         dc.tag = e->u_epoch;
+        dc.xparity = (int)(e->pending_xseq & 1ull);
+        dc.xtag = (unsigned int)(e->pending_xseq % 0xFFFFFFFFull) + 1u;
         dc.n_blocks = ca.n_cols * ca.RS;
         e->pending = false;
     }
@@ -735,6 +755,7 @@ int mppi_solve_async(mppi_engine* e, void* stream)
         // the combine is not launched yet: it rides at the front of the next solve's launch, or
         // is flushed by the first call that needs this solve's results
         e->pending = true;
+        e->pending_mode = 1;
         e->pending_idx = e->solve_idx;
         e->pending_stream = st;
     } else {
@@ -745,6 +766,12 @@ int mppi_solve_async(mppi_engine* e, void* stream)
     e->solve_idx += 1;
     e->have_solve = true;
     return MPPI_OK;
+}
+
+int mppi_flush_async(mppi_engine* e)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    return flush_pending(e);
 }
 
 int mppi_sync_act(mppi_engine* e, float* next_act)
@@ -952,9 +979,20 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);      // (flushes a pending combine first)
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial,
-                         true);
-    return rc;
+    if (e->strict || e->pipeline) {
+        return enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial,
+                               true);
+    }
+    // the same 256-thread combine the direct exchange runs, so that both transports add this
+    // rank's partial in the same order (equal bits)
+    mppi::CombineArgs ca;
+    e->u_epoch += 1;
+    if (e->u_epoch == 0) e->u_epoch = 1;
+    fill_own_combine(e, ca, e->solve_idx, e->u_epoch, 0, 0, d_partial);
+    mppi::LaunchTiming tm;
+    if ((rc = prof_pair(e, tm, 1))) return rc;
+    HIPCHK(mppi::launch_combine_small(ca, st, tm));
+    return MPPI_OK;
 }
 
 int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts, void* stream)
@@ -1055,6 +1093,7 @@ int mppi_xchg_set_timeout(mppi_engine* e, double seconds)
 int mppi_xchg_close(mppi_engine* e)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
+    e->pending = false;         // an exchange nobody waited for
     if (e->last_stream) (void)hipStreamSynchronize(e->last_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->xg_opened) (void)hipIpcCloseMemHandle(p);
@@ -1070,10 +1109,23 @@ int mppi_solve_exchange_async(mppi_engine* e, void* stream)
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    int rc = enqueue_rollout(e, st);
+    const bool defer = e->defer && !e->pipeline;
+    int rc = enqueue_rollout(e, st, defer);
     if (rc) return rc;
-    rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr, true);
-    if (rc) return rc;
+    if (defer && !e->strict) {
+        // like mppi_solve_async: the combine (here: rank-local combine, exchange, finish) rides in
+        // the next solve's rollout launch -- the peers' words arrive while this rank draws the
+        // next solve's noise -- or is flushed by the first call that needs the results
+        e->pending = true;
+        e->pending_mode = 2;
+        e->pending_xseq = e->xg_seq;
+        e->pending_idx = e->solve_idx;
+        e->pending_stream = st;
+    } else {
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr,
+                             true);
+        if (rc) return rc;
+    }
     e->xg_seq += 1;
     e->solve_idx += 1;
     e->have_solve = true;

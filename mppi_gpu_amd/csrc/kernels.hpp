@@ -183,6 +183,8 @@ struct DeferredCombine {
     const CombineArgs* args;          // device copy; solve_idx and tag are taken from here instead
     unsigned long long solve_idx;
     unsigned int tag;
+    unsigned int xtag;                // final_mode 2: this exchange's inbox tag and parity
+    int xparity;
     int n_blocks;                     // 0 = nothing rides with this launch
 };
 

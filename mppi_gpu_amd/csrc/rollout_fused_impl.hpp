@@ -423,6 +423,8 @@ __device__ __forceinline__ void fused_kernel_body(const RolloutHot& h, const Def
             CombineArgs a = *d.args;
             a.solve_idx = d.solve_idx;
             a.tag = d.tag;
+            a.x.tag = d.xtag;
+            a.x.parity = d.xparity;
             combine_body<kRolloutThreads, kSmallCombineNR>(
                 a, (int)blockIdx.x,
                 carve_combine_smem<kRolloutThreads>(reinterpret_cast<float*>(smem_raw)));

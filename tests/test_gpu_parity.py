@@ -472,7 +472,7 @@ def test_direct_exchange_in_process_equals_gathered_finish(gpu):
     ref = make()
     L = ref[0].partial_len()
     ref_acts = []
-    for it in range(3):
+    for it in range(6):
         gathered = torch.zeros(G, L, device="cuda", dtype=torch.float32)
         torch.cuda.synchronize()
         for g, s in enumerate(ref):
@@ -493,9 +493,22 @@ def test_direct_exchange_in_process_equals_gathered_finish(gpu):
     for it in range(3):
         for s in eng:
             s.solve_exchange_async()          # each on its engine's own stream
-        acts = [s.sync_act() for s in eng]
+        for s in eng:
+            s.flush_async()                   # one host thread drives all three: launch all the
+        acts = [s.sync_act() for s in eng]    # deferred exchanges before waiting on the first
         for a in acts:
             assert np.array_equal(a, ref_acts[it]), it
+    # three more solves enqueued back to back: the exchange of solve j rides in the rollout launch
+    # of solve j+1 of the same engine and waits there for the other engines' words (the grids are
+    # small enough for the three launches to be resident together)
+    for it in range(3):
+        for s in eng:
+            s.solve_exchange_async()
+    for s in eng:
+        s.flush_async()
+    acts = [s.sync_act() for s in eng]
+    for a in acts:
+        assert np.array_equal(a, ref_acts[5])
     for s in eng:
         assert np.array_equal(s.get_u(), U_ref)
         s.close()
