@@ -175,6 +175,11 @@ def main():
     assert np.isfinite(act).all(), "non-finite action"
 
     roof = None
+    # mode 0 lets the combine ride in the next rollout launch while launches are short (at most two
+    # tiles per block, engine.hip enqueue_rollout); longer ones launch it on its own
+    n_tiles = -(-K * geo["chunks"] // geo["block"])
+    riding = (args.pipeline == 0 and not args.strict and not args.blocking
+              and n_tiles <= 2 * geo["grid"])
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
@@ -185,16 +190,35 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-            ent = tj["entries"].get(f"{args.workload}:chunks={geo['chunks']}")
+            kind = "ride" if riding else "plain"
+            ent = tj["entries"].get(f"{args.workload}:chunks={geo['chunks']}:{kind}")
             if ent and not geo["strict"]:
                 traffic = ent["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        roof = {"bound": "hbm", "kernel": "k_rollout_fused" if not geo["strict"] else "k_rollout_stream",
+        kname = ("k_rollout_stream" if geo["strict"] else
+                 "k_rollout_ride (rollout of solve j + combine of solve j-1 in one launch)" if riding
+                 else "k_rollout_fused")
+        roof = {"bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
                 "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
+        if riding and sharded is None:
+            # for reference, outside the timed region: the two kernels on their own (eager mode,
+            # one rollout launch + one combine launch per solve)
+            m.set_pipeline(2)
+            m.set_profiling(1)
+            for _ in range(64):
+                m.solve_async()
+            m.sync_act()
+            r_ms, _ = m.kernel_ms(0)
+            c2_ms, _ = m.kernel_ms(1)
+            m.set_profiling(0)
+            m.set_pipeline(0)
+            roof["solo"] = {"rollout_kernel_ms": round(r_ms, 5), "combine_kernel_ms": round(c2_ms, 5),
+                            "rollout_frac": round(ab / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                            if r_ms > 0 else None}
 
     if rank == 0:
         value = N * K * args.steps / dt_s

@@ -94,7 +94,10 @@ __device__ __forceinline__ void publish_control(const CombineArgs& a, int n, flo
     float* Uout = a.U + (size_t)((a.solve_idx + 1ull) & 1ull) * a.TA;
     if (n < a.A) {
         a.act_dev[n] = unew;
-        if (a.act_host) a.act_host[n] = unew;
+        if (a.act_host)      // one 8-byte store over PCIe: the host may poll for it (mppi_get_act)
+            __hip_atomic_store(a.act_host + n,
+                               ((unsigned long long)a.act_tag << 32) | __float_as_uint(unew),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
         Uout[n - a.A] = unew;
     }

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -109,8 +110,9 @@ struct mppi_engine {
     float *d_pm = nullptr, *d_ps = nullptr, *d_pN = nullptr;
     int part_cap = 0;
     float* d_act = nullptr;
-    float* h_act = nullptr;     // pinned + mapped
-    float* h_act_dev = nullptr; // device alias of h_act
+    unsigned long long* h_act = nullptr;      // pinned + mapped: A words {action bits, act_seq}
+    unsigned long long* h_act_dev = nullptr;  // device alias of h_act
+    unsigned int act_seq = 0;   // final combines launched; the tag of the newest action
     float* d_local_partial = nullptr;  // TA+2 (sharded path)
     mppi::RolloutArgs* d_args = nullptr;   // launch descriptor in device memory
     mppi::RolloutArgs h_args_last;         // what d_args currently holds
@@ -152,9 +154,6 @@ struct mppi_engine {
     hipStream_t pending_stream = nullptr;
     unsigned long long* d_slab_tag = nullptr;   // [kMaxSmallSplits][TA] tagged split sums + nabla
     unsigned int u_epoch = 0;               // combines launched through the small path; tag source
-    mppi::CombineArgs* d_cargs = nullptr;   // device copy of the riding combine's arguments
-    mppi::CombineArgs h_cargs_last;
-    bool cargs_valid = false;
     int* d_err = nullptr;                   // device watchdog word: 1 = peer exchange timed out,
     int* h_err = nullptr;                   // 2 = wait for a riding combine timed out
     int* h_err_dev = nullptr;               // (pinned + mapped mirror the kernels also write)
@@ -366,11 +365,18 @@ void fill_gen_args(const mppi_engine_t* e, mppi::GenArgs& ga, unsigned long long
 
 // the final combine of solve `idx` over this engine's own block partials, in the 256-thread shape
 // that rides in a rollout launch or is flushed stand-alone
+unsigned int next_act_tag(mppi_engine_t* e)
+{
+    e->act_seq += 1;
+    if (e->act_seq == 0) e->act_seq = 1;       // 0 is the tag of the zero-initialised words
+    return e->act_seq;
+}
+
 // mode: 0 rank partial -> partial_out, 1 final, 2 rank partial -> peer exchange (sequence number
 // xseq) -> final
-void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long long idx,
+void fill_own_combine(mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long long idx,
                       unsigned int tag, int mode = 1, unsigned long long xseq = 0,
-                      float* partial_out = nullptr, bool per_solve_fields = true)
+                      float* partial_out = nullptr)
 {
     memset(&ca, 0, sizeof ca);
     ca.dev = e->d_state;
@@ -384,6 +390,7 @@ void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned lo
     ca.tag = tag;
     ca.act_dev = e->d_act;
     ca.act_host = e->h_act_dev;
+    if (mode != 0) ca.act_tag = next_act_tag(e);
     ca.slab = e->d_slab;
     ca.slab_tag = e->d_slab_tag;
     ca.tickets = e->d_tickets;
@@ -399,10 +406,8 @@ void fill_own_combine(const mppi_engine_t* e, mppi::CombineArgs& ca, unsigned lo
         ca.x.rank = e->xg_rank;
         ca.x.W = e->xg_W;
         ca.x.timeout_ticks = (unsigned long long)(e->xg_timeout_s * 1e8);   // 100 MHz clock
-        if (per_solve_fields) {
-            ca.x.parity = (int)(xseq & 1ull);
-            ca.x.tag = (unsigned int)(xseq % 0xFFFFFFFFull) + 1u;
-        }
+        ca.x.parity = (int)(xseq & 1ull);
+        ca.x.tag = (unsigned int)(xseq % 0xFFFFFFFFull) + 1u;
     }
     const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
     ca.row_splits = env ? atoi(env) : 0;
@@ -425,6 +430,29 @@ int flush_pending(mppi_engine_t* e)
     return MPPI_OK;
 }
 
+// the newest action, from the pinned words the combine kernels write
+void read_action(const mppi_engine_t* e, float* next_act)
+{
+    for (int i = 0; i < e->A; ++i) {
+        const unsigned int bits = (unsigned int)__atomic_load_n(&e->h_act[i], __ATOMIC_ACQUIRE);
+        memcpy(&next_act[i], &bits, sizeof(float));
+    }
+}
+
+// report (and clear) what a device-side time-out left in the watchdog word
+int check_watchdog(mppi_engine_t* e)
+{
+    if (!e->h_err || !*e->h_err) return MPPI_OK;
+    const int code = *e->h_err;
+    *e->h_err = 0;
+    (void)hipMemset(e->d_err, 0, sizeof(int));
+    if (code == 1)
+        return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
+                    "solve %llu", e->xg_timeout_s, e->solve_idx);
+    return fail(MPPI_ESTATE, "device watchdog %d: a block waited 2 s for the combine riding in "
+                "its own launch", code);
+}
+
 // everything enqueued by this engine has run, nothing is pending
 int settle(mppi_engine_t* e)
 {
@@ -441,8 +469,20 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     if (!e->data_set) return fail(MPPI_ESTATE, "solve before mppi_set_data");
     int rc = ensure_geometry(e);
     if (rc) return rc;
-    if (e->pending && (!carry || e->strict || e->pending_stream != st)) {
-        if ((rc = flush_pending(e))) return rc;
+    if (e->pending) {
+        // Riding pays while the launch is short: the riding variant of the kernel is a few per
+        // cent slower per tile (measured 4 %) and the combine blocks take slots from the first
+        // rollout blocks, against the ~8 us of a stand-alone combine launch.  With more than two
+        // tiles per block the pending combine is launched on its own instead (same kernel code,
+        // same bits).
+        static const int max_tiles = [] {
+            const char* env = getenv("MPPI_RIDE_MAX_TILES");   // tuning aid
+            return env ? atoi(env) : 2;
+        }();
+        const bool short_launch = (long long)e->n_tileblk <= (long long)max_tiles * e->grid;
+        if (!carry || e->strict || e->pending_stream != st || !short_launch) {
+            if ((rc = flush_pending(e))) return rc;
+        }
     }
     e->last_stream = st;
     if (e->injected && e->inj_dirty) {
@@ -481,23 +521,10 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     mppi::DeferredCombine dc;
     memset(&dc, 0, sizeof dc);
     if (e->pending) {       // same stream, fused kernel: the pending combine rides in this launch
-        mppi::CombineArgs ca;
-        // per-solve fields (solve index, tags, exchange parity) travel by value
-        fill_own_combine(e, ca, 0, 0, e->pending_mode, 0, nullptr, false);
-        if (!e->cargs_valid || memcmp(&ca, &e->h_cargs_last, sizeof ca) != 0) {
-            HIPCHK(hipMemcpyAsync(e->d_cargs, &ca, sizeof ca, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
-            e->h_cargs_last = ca;
-            e->cargs_valid = true;
-        }
-        dc.args = e->d_cargs;
-        dc.solve_idx = e->pending_idx;
         e->u_epoch += 1;
         if (e->u_epoch == 0) e->u_epoch = 1;
-        dc.tag = e->u_epoch;
-        dc.xparity = (int)(e->pending_xseq & 1ull);
-        dc.xtag = (unsigned int)(e->pending_xseq % 0xFFFFFFFFull) + 1u;
-        dc.n_blocks = ca.n_cols * ca.RS;
+        fill_own_combine(e, dc.c, e->pending_idx, e->u_epoch, e->pending_mode, e->pending_xseq);
+        dc.n_blocks = dc.c.n_cols * dc.c.RS;
         e->pending = false;
     }
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
@@ -534,6 +561,7 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     ca.U = e->d_U;
     ca.act_dev = e->d_act;
     ca.act_host = e->h_act_dev;
+    if (mode != 0) ca.act_tag = next_act_tag(e);
     ca.partial_out = partial_out;
     ca.slab = e->d_slab;
     ca.tickets = e->d_tickets;
@@ -628,9 +656,8 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
         HIPCHK(hipMalloc(&e->d_slab_tag, words * sizeof(unsigned long long)));
         HIPCHK(hipMemset(e->d_slab_tag, 0, words * sizeof(unsigned long long)));
     }
-    HIPCHK(hipMalloc(&e->d_cargs, sizeof(mppi::CombineArgs)));
-    HIPCHK(hipHostMalloc(&e->h_act, 4 * sizeof(float), hipHostMallocMapped));
-    memset(e->h_act, 0, 4 * sizeof(float));
+    HIPCHK(hipHostMalloc(&e->h_act, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(e->h_act, 0, 4 * sizeof(unsigned long long));
     HIPCHK(hipHostGetDevicePointer((void**)&e->h_act_dev, e->h_act, 0));
     if (verbose)
         printf("mppi_gpu_amd: K=%d T=%d S=%d A=%d dt=%g (offset %lld)\n", K, T, S, A, dt,
@@ -683,7 +710,6 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_err);
     if (e->h_err) (void)hipHostFree(e->h_err);
     (void)hipFree(e->d_slab_tag);
-    (void)hipFree(e->d_cargs);
     for (auto& list : e->ev)
         for (hipEvent_t ev : list) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_state);
@@ -781,19 +807,8 @@ int mppi_sync_act(mppi_engine* e, float* next_act)
         int rc = settle(e);
         if (rc) return rc;
     }
-    if (next_act)
-        for (int i = 0; i < e->A; ++i) next_act[i] = e->h_act[i];
-    if (e->h_err && *e->h_err) {
-        const int code = *e->h_err;
-        *e->h_err = 0;
-        (void)hipMemset(e->d_err, 0, sizeof(int));
-        if (code == 1)
-            return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
-                        "solve %llu", e->xg_timeout_s, e->solve_idx);
-        return fail(MPPI_ESTATE, "device watchdog %d: a rollout block waited 2 s for the combine "
-                    "riding in its own launch", code);
-    }
-    return MPPI_OK;
+    if (next_act) read_action(e, next_act);
+    return check_watchdog(e);
 }
 
 int mppi_get_act(mppi_engine* e, float* next_act)
@@ -801,7 +816,27 @@ int mppi_get_act(mppi_engine* e, float* next_act)
     if (!e || !next_act) return fail(MPPI_EINVAL, "null argument");
     int rc = mppi_solve_async(e, nullptr);
     if (rc) return rc;
-    return mppi_sync_act(e, next_act);
+    if ((rc = flush_pending(e))) return rc;
+    // The closed-loop call: poll the pinned words the combine kernel writes the action into
+    // (8-byte {value, tag} stores) instead of sleeping in hipStreamSynchronize, whose wake-up
+    // costs more than the solve at K = 1e4; after 300 us of polling fall back to the blocking
+    // wait.  Later calls on the engine are stream-ordered behind the solve as always.
+    const unsigned int want = e->act_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool all = true;
+        for (int i = 0; i < e->A; ++i) {
+            const unsigned long long w = __atomic_load_n(&e->h_act[i], __ATOMIC_ACQUIRE);
+            all = all && (unsigned int)(w >> 32) == want;
+        }
+        if (all) break;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+            if ((rc = settle(e))) return rc;
+            break;
+        }
+    }
+    read_action(e, next_act);
+    return check_watchdog(e);
 }
 
 int mppi_get_u(mppi_engine* e, float* u)
@@ -1011,6 +1046,7 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
     ca.U = e->d_U;
     ca.act_dev = e->d_act;
     ca.act_host = e->h_act_dev;
+    ca.act_tag = next_act_tag(e);
     ca.solve_idx = e->solve_idx;
     ca.final_mode = 1;
     HIPCHK(mppi::launch_finish_gathered(ca, d_gathered, n_parts, st));

@@ -150,7 +150,8 @@ struct CombineArgs {
     // final mode: update + shift U, publish action, bump solve_idx
     float* U;              // base of the 2 x TA double buffer
     float* act_dev;        // [4] device copy of the action
-    float* act_host;       // pinned, host-mapped; may be null
+    unsigned long long* act_host;   // pinned, host-mapped words {action bits, act_tag}; may be null
+    unsigned int act_tag;  // the engine's count of final combines: lets the host poll for THIS action
     // partial mode: out[0]=beta_g, out[1]=S_g, out[2..2+TA)=N_g
     float* partial_out;
     float* slab;           // [kMaxRowSplits][TA] row-split sums (RS > 1)
@@ -180,11 +181,8 @@ struct CombineArgs {
 // wait for them.  (Letting the rollout blocks add the row splits' sums themselves saves a hop but
 // multiplies the polled words by RS + 2: measured slower, 17.4 vs 17.0 us at C2.)
 struct DeferredCombine {
-    const CombineArgs* args;          // device copy; solve_idx and tag are taken from here instead
-    unsigned long long solve_idx;
-    unsigned int tag;
-    unsigned int xtag;                // final_mode 2: this exchange's inbox tag and parity
-    int xparity;
+    CombineArgs c;                    // by value: a pointer would put one more memory round
+                                      // trip in front of the combine the rollout blocks wait for
     int n_blocks;                     // 0 = nothing rides with this launch
 };
 

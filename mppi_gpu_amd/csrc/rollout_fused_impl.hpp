@@ -168,6 +168,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                 float* uflat = reinterpret_cast<float*>(ulds);
                 float* ucflat = reinterpret_cast<float*>(uclds);
                 const unsigned long long* fin_p = g.fin_tag;
+                const unsigned int tag_want = d.c.tag;
                 for (int idx = threadIdx.x; idx < NBTp * 4; idx += kRolloutThreads) {
                     float unew = 0.0f;
                     if (idx < TA) {
@@ -175,7 +176,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         for (;;) {
                             const unsigned long long w = __hip_atomic_load(
                                 fin_p + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned int)(w >> 32) == d.tag) {
+                            if ((unsigned int)(w >> 32) == tag_want) {
                                 unew = __uint_as_float((unsigned int)w);
                                 break;
                             }
@@ -420,13 +421,8 @@ __device__ __forceinline__ void fused_kernel_body(const RolloutHot& h, const Def
             __builtin_amdgcn_s_setprio(3);
             MPPI_STAMP(0);
             extern __shared__ __align__(16) unsigned char smem_raw[];
-            CombineArgs a = *d.args;
-            a.solve_idx = d.solve_idx;
-            a.tag = d.tag;
-            a.x.tag = d.xtag;
-            a.x.parity = d.xparity;
             combine_body<kRolloutThreads, kSmallCombineNR>(
-                a, (int)blockIdx.x,
+                d.c, (int)blockIdx.x,
                 carve_combine_smem<kRolloutThreads>(reinterpret_cast<float*>(smem_raw)));
             MPPI_STAMP(10);
             return;
