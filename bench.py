@@ -70,8 +70,11 @@ def cpu_baseline(A, K, T, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--ramp-ms", type=float, default=30.0,
+                    help="untimed solves for this long before the W warm-up steps, so that short "
+                         "runs are not measured at idle clocks (0 = off)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
@@ -96,7 +99,7 @@ def main():
                          "with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--inject", action="store_true",
                     help="ANALYSIS ONLY: injected-noise mode (no sampling); not a valid bench result")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=32,
                     help="record HIP events around the kernels of every n-th timed solve")
     args = ap.parse_args()
 
@@ -155,6 +158,20 @@ def main():
         torch.cuda.synchronize()
         m.sync_act()          # the engine's own stream (same HIP runtime as torch's: see _capi)
 
+    if args.ramp_ms > 0:                       # clock ramp; every rank takes the same decisions
+        t_r = time.perf_counter()
+        for _batch in range(2000):
+            for _ in range(50):
+                step()
+            m.sync_act()
+            go = time.perf_counter() - t_r < args.ramp_ms * 1e-3
+            if dist is not None:
+                gt = torch.tensor([1 if go else 0], dtype=torch.int32,
+                                  device="cpu" if args.rehearse_one_gpu else "cuda")
+                dist.all_reduce(gt, op=dist.ReduceOp.MIN)
+                go = bool(gt.item())
+            if not go:
+                break
     for _ in range(args.warmup):
         step()
     fence()
