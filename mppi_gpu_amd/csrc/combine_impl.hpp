@@ -175,11 +175,16 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     //      exp-sums, the first batch of weighted-noise rows and the nominal control; beta,
     //      nabla and the rescale factors are computed while they are in flight -------------
     float mreg[PT], sreg[PT];
+    const int jmax = (a.n_parts + THREADS - 1) / THREADS;   // sweeps that hold any partial at all
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const int p = tid + j * THREADS;
-        mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
-        sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
+        mreg[j] = INFINITY;
+        sreg[j] = 0.0f;
+        if (j < jmax) {                                      // block-uniform
+            mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
+            sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
+        }
     }
     float v[NR];
 #pragma unroll
@@ -190,6 +195,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     float uin = 0.0f;
     if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
 
+    MPPI_CSTAMP(1);
     float mloc = mreg[0];
 #pragma unroll
     for (int j = 1; j < PT; ++j) mloc = fminf(mloc, mreg[j]);
@@ -203,10 +209,12 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     float sloc = 0.0f;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-        const int p = tid + j * THREADS;
-        const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
-        if (p < a.n_parts) r_lds[p] = r;
-        sloc += r * sreg[j];
+        if (j < jmax) {      // block-uniform: no exponentials for sweeps without partials
+            const int p = tid + j * THREADS;
+            const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
+            if (p < a.n_parts) r_lds[p] = r;
+            sloc += r * sreg[j];
+        }
     }
     sloc = wave_sum(sloc);
     if (lane == 0) scal[NW + wave] = sloc;
@@ -215,6 +223,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
 #pragma unroll
     for (int i = 0; i < NW; ++i) nabla += scal[NW + i];
 
+    MPPI_CSTAMP(2);
     float acc = 0.0f;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -243,6 +252,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
         for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
     }
 
+    MPPI_CSTAMP(3);
     // `mine`: this rank's finished sums for the block's 16 columns (threads 0..15 of the block
     // that applies them); apply_blk is block-uniform
     float mine = tot;
@@ -270,6 +280,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
                 if (p2) t2 += v2;
             }
             mine = t2 + tot;
+            MPPI_CSTAMP(4);
             if (timed_out) {
                 *a.x.err_dev = 2;
                 if (a.x.err_host) *a.x.err_host = 2;

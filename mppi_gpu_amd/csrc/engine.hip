@@ -411,6 +411,9 @@ void fill_own_combine(mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long lon
     }
     const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
     ca.row_splits = env ? atoi(env) : 0;
+#ifdef MPPI_TRACE
+    ca.trace = mppi::g_mppi_trace_buf;
+#endif
     (void)mppi::combine_small_prepare(ca);
 }
 
@@ -426,6 +429,9 @@ int flush_pending(mppi_engine_t* e)
     int rc = prof_pair(e, tm, 1);
     if (rc) return rc;
     e->pending = false;
+#ifdef MPPI_TRACE
+    ca.trace = nullptr;      // the analysis looks at the riding role only
+#endif
     HIPCHK(mppi::launch_combine_small(ca, e->pending_stream, tm));
     return MPPI_OK;
 }

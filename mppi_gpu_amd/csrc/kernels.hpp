@@ -167,7 +167,18 @@ struct CombineArgs {
     XchgArgs x;            // final_mode 2 only
     int row_splits;        // 0 = auto
     int n_cols, RS;        // filled by the launcher: column blocks and row splits of the grid
+#ifdef MPPI_TRACE
+    unsigned long long* trace;
+#endif
 };
+#ifdef MPPI_TRACE
+#define MPPI_CSTAMP(i)                                                                   \
+    do {                                                                                 \
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MPPI_CSTAMP(i) do { } while (0)
+#endif
 
 // A combine that rides at the front of the NEXT solve's rollout launch (mppi_solve_async back to
 // back): the first n_blocks blocks of the grid play the combine role for solve `solve_idx` while

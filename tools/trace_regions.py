@@ -35,7 +35,7 @@ if ride:
         m.solve_async()                              # the last launch carried a combine
     m.sync_act()
     import math
-    rs = max(1, math.ceil(grid / 160))
+    rs = max(1, math.ceil(grid / 320))
     nb = math.ceil(T * A / 16) * rs
 else:
     m.solve_async(); m.sync_act()
@@ -47,6 +47,11 @@ if nb:
     print("combine-role blocks:", nb, " start (10 ns ticks after first block) p50/max",
           np.median(tc[:, 0] - t00), (tc[:, 0] - t00).max(), " end p50/max",
           np.median(tc[:, 10] - t00), (tc[:, 10] - t00).max())
+    for i, nm in [(1, "loads landed (m,s)"), (2, "beta/nabla done"), (3, "rows reduced"), (4, "splits met"), (10, "done")]:
+        r = tc[:, i] - tc[:, 0]
+        r = r[tc[:, i] > 0]
+        if len(r):
+            print(f"   combine {nm:20s} p50 {np.median(r):6.0f}  max {r.max():6d}  (n={len(r)})")
     buf = buf[nb:]
     print("rollout blocks start p50/max", np.median(buf[:, 0].astype(np.int64) - t00),
           (buf[:, 0].astype(np.int64) - t00).max(), " end max", (buf[:, 10].astype(np.int64) - t00).max())
