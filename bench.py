@@ -81,9 +81,9 @@ def main():
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events")
-    ap.add_argument("--pipeline", type=int, default=0, choices=(0, 1, 2),
+    ap.add_argument("--pipeline", type=int, default=0, choices=(0, 1),
                     help="mppi_set_pipeline mode: 0 deferred combine (default: back-to-back solves "
-                         "are one launch each), 1 noise prefetch (experiment), 2 eager (rollout + "
+                         "are one launch each while launches are short), 1 eager (rollout + "
                          "combine launch per solve)")
     ap.add_argument("--blocking", action="store_true",
                     help="analysis: every step is a blocking get_act (the closed-loop call), not an "
@@ -224,7 +224,7 @@ def main():
         if riding and sharded is None:
             # for reference, outside the timed region: the two kernels on their own (eager mode,
             # one rollout launch + one combine launch per solve)
-            m.set_pipeline(2)
+            m.set_pipeline(1)
             m.set_profiling(1)
             for _ in range(64):
                 m.solve_async()

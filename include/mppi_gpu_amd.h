@@ -104,19 +104,19 @@ int mppi_set_ref_compat(mppi_engine* e, int on);
  * anchor.  max_blocks caps the persistent grid (0 = auto). */
 int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
 
-/* How consecutive solves are enqueued (results are identical in every mode):
+/* How consecutive solves are enqueued:
  *   0  deferred combine (default).  mppi_solve_async launches the rollout only; the combine
  *      (beta, nabla, update, shift, action) is launched by whatever comes next: if that is another
- *      mppi_solve_async on the same stream, it RIDES in that launch -- the first blocks of the
- *      grid play the combine role while the rollout blocks draw their Philox / Box-Muller noise
- *      (half of the kernel, and independent of the controls), and each rollout block waits on an
- *      agent-scope counter for the finished controls before it stages them; anything that needs
- *      the results (mppi_sync_act, mppi_get_act, mppi_get_u, mppi_get_inf, mppi_set_data, ...)
- *      flushes it as a stand-alone launch first.  mppi_get_act alone is therefore the same two
- *      launches as mode 2; back-to-back solves become ONE launch each.
- *   1  noise prefetch (experiment, slower on MI355X: DESIGN.md section 2): the combine launch of
- *      solve j also draws the noise of solve j+1 into a second buffer.
- *   2  eager: every solve launches its rollout and its combine at once. */
+ *      mppi_solve_async on the same stream and the launch is short (at most two tiles per block),
+ *      it RIDES in that launch -- the first blocks of the grid play the combine role while the
+ *      rollout blocks draw their Philox / Box-Muller noise (half of the kernel, and independent of
+ *      the controls), and each rollout block polls tagged words for the finished controls before
+ *      it stages them; otherwise, and for anything that needs the results (mppi_sync_act,
+ *      mppi_get_act, mppi_get_u, mppi_get_inf, mppi_set_data, ...), it is launched on its own
+ *      first -- same device function, same bits.  mppi_get_act alone is therefore two launches;
+ *      back-to-back solves at K = 1e4 become ONE launch each.
+ *   1  eager: every solve launches its rollout and a 1024-thread combine at once (another
+ *      summation order: results agree with mode 0 to rounding, not bit for bit). */
 int mppi_set_pipeline(mppi_engine* e, int mode);
 
 /* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */

@@ -163,7 +163,7 @@ class PointMassModel:
         check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
 
     def set_pipeline(self, mode):
-        """0 deferred combine (default), 1 noise prefetch (experiment), 2 eager; see the header."""
+        """0 deferred combine (default), 1 eager; see the header."""
         check(self._lib.mppi_set_pipeline(self._h, int(mode)))
 
     def geometry(self):

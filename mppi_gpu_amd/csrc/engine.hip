@@ -4,7 +4,8 @@
 // PointMassModel (include/point_mass.hpp:23-116) -- but as flat structure-of-arrays buffers:
 // no per-sample objects, no device heap, no host loop over the horizon, no synchronisation
 // between the stages of a solve (reference src/point_mass.cu:129-203 syncs 8 times and
-// launches >= 3*T kernels per solve).  A solve is two launches on one stream.
+// launches >= 3*T kernels per solve).  A solve is a rollout launch and a combine launch on one
+// stream; with solves back to back the combine rides in the next rollout launch.
 #include "../../include/mppi_gpu_amd.h"
 #include "kernels.hpp"
 
@@ -99,13 +100,9 @@ struct mppi_engine {
     // device memory
     mppi::DevState* d_state = nullptr;
     float* d_U = nullptr;       // 2 x TA
-    float* d_Eint = nullptr;    // noise buffer 0 (tile layout)
-    float* d_Eint2 = nullptr;   // noise buffer 1 (pipelined mode alternates by solve parity)
+    float* d_Eint = nullptr;    // noise (tile layout)
     size_t eint_floats = 0;
     float* last_E = nullptr;    // buffer the last rollout used
-    int pipeline = 0;           // 1 = the combine launch of solve j also draws the noise of j+1
-                                // (measured slower than in-place sampling on MI355X: default off)
-    long long noise_ready_idx = -1;   // solve index whose noise is (being) generated, -1 = none
     float* d_cost = nullptr;
     float *d_pm = nullptr, *d_ps = nullptr, *d_pN = nullptr;
     int part_cap = 0;
@@ -228,7 +225,7 @@ int ensure_geometry(mppi_engine_t* e)
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             ncu = prop.multiProcessorCount;
-        const bool in_kernel_sampling = !e->injected && !e->pipeline;
+        const bool in_kernel_sampling = !e->injected;
         const int per_cu = strict ? 0 : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
         max_blocks = per_cu > 0 ? 3 * per_cu * ncu : 2048;
         if (max_blocks > 3072) max_blocks = 3072;
@@ -246,15 +243,10 @@ int ensure_geometry(mppi_engine_t* e)
         if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
         e->d_Eint = nullptr;
         e->eint_floats = 0;
-        if (e->d_Eint2) HIPCHK(hipFree(e->d_Eint2));
-        e->d_Eint2 = nullptr;
         HIPCHK(hipMalloc(&e->d_Eint, need * sizeof(float)));
-        HIPCHK(hipMalloc(&e->d_Eint2, need * sizeof(float)));
         e->eint_floats = need;
     }
-    e->noise_ready_idx = -1;
     e->last_E = e->d_Eint;
-    HIPCHK(hipMemsetAsync(e->d_Eint2, 0, e->eint_floats * sizeof(float), e->stream));
     HIPCHK(hipMemsetAsync(e->d_Eint, 0, e->eint_floats * sizeof(float), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (grid > e->part_cap) {
@@ -349,22 +341,6 @@ int prof_pair(mppi_engine_t* e, mppi::LaunchTiming& tm, int which)
     return MPPI_OK;
 }
 
-void fill_gen_args(const mppi_engine_t* e, mppi::GenArgs& ga, unsigned long long idx, float* buf)
-{
-    ga.Eint = buf;
-    ga.seed = e->seed;
-    ga.blk_base = idx * (unsigned long long)e->NBT;
-    ga.k_offset = e->k_offset;
-    ga.n_lanes = (long long)e->n_tileblk * mppi::kRolloutThreads;
-    ga.K = e->K;
-    ga.NBT = e->NBT;
-    ga.logC = e->logC;
-    ga.nq = e->nq;
-    for (int i = 0; i < 4; ++i) ga.sigma[i] = e->sigma[i];
-}
-
-// the final combine of solve `idx` over this engine's own block partials, in the 256-thread shape
-// that rides in a rollout launch or is flushed stand-alone
 unsigned int next_act_tag(mppi_engine_t* e)
 {
     e->act_seq += 1;
@@ -495,17 +471,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, e->C, e->nq, st));
         e->inj_dirty = false;
     }
-    // pipelined mode: the noise of this solve was drawn by the previous solve's combine launch
-    // (or is drawn now by k_generate if nothing was prefetched) into the buffer of this solve's
-    // parity; the rollout runs its no-sampling variant on it.
-    const bool pipelined = e->pipeline && !e->injected && !e->strict;
-    float* Ecur = pipelined ? ((e->solve_idx & 1ull) ? e->d_Eint2 : e->d_Eint) : e->d_Eint;
-    if (pipelined && e->noise_ready_idx != (long long)e->solve_idx) {
-        mppi::GenArgs ga;
-        fill_gen_args(e, ga, e->solve_idx, Ecur);
-        HIPCHK(mppi::launch_generate(e->A, ga, st));
-        e->noise_ready_idx = (long long)e->solve_idx;
-    }
+    float* Ecur = e->d_Eint;
 
     mppi::RolloutArgs ra;
     memset(&ra, 0, sizeof ra);
@@ -536,7 +502,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
     mppi::LaunchTiming tm;
     if ((rc = prof_pair(e, tm, 0))) return rc;
-    const bool sample_in_kernel = !e->injected && !pipelined;
+    const bool sample_in_kernel = !e->injected;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
     else
@@ -551,12 +517,12 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
 
 int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const float* s,
                     const float* N, long long ms, long long ss, long long Ns, int n_parts,
-                    int mode, float* partial_out, bool prefetch_noise = false)
+                    int mode, float* partial_out)
 {
     if (n_parts < 1 || n_parts > mppi::kMaxParts)
         return fail(MPPI_EINVAL, "n_parts %d out of range", n_parts);
     mppi::CombineArgs ca;
-    memset(&ca, 0, sizeof ca);                 // (U_tag = null: only the small combine tags)
+    memset(&ca, 0, sizeof ca);                 // (slab_tag = null: ticketed row splits)
     ca.dev = e->d_state;
     ca.m = m; ca.s = s; ca.N = N;
     ca.m_stride = ms; ca.s_stride = ss; ca.N_stride = Ns;
@@ -595,16 +561,7 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
         int rc = prof_pair(e, tm, 1);
         if (rc) return rc;
     }
-    if (prefetch_noise && e->pipeline && !e->injected && !e->strict && !getenv("MPPI_DEBUG_NOPREFETCH")) {
-        // the blocks this launch does not need for combining draw the NEXT solve's noise
-        mppi::GenArgs ga;
-        const unsigned long long nxt = e->solve_idx + 1ull;
-        fill_gen_args(e, ga, nxt, (nxt & 1ull) ? e->d_Eint2 : e->d_Eint);
-        HIPCHK(mppi::launch_combine(ca, st, tm, &ga, e->A));
-        e->noise_ready_idx = (long long)nxt;
-    } else {
-        HIPCHK(mppi::launch_combine(ca, st, tm));
-    }
+    HIPCHK(mppi::launch_combine(ca, st, tm));
     return MPPI_OK;
 }
 
@@ -721,7 +678,6 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_state);
     (void)hipFree(e->d_U);
     (void)hipFree(e->d_Eint);
-    (void)hipFree(e->d_Eint2);
     (void)hipFree(e->d_cost);
     (void)hipFree(e->d_pm);
     (void)hipFree(e->d_ps);
@@ -747,7 +703,6 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
         if (rc_) return rc_;
     }
     for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
-    e->noise_ready_idx = -1;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
     e->have_solve = false;
     HIPCHK(hipMemcpy(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice));
@@ -780,7 +735,7 @@ int mppi_solve_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    const bool defer = e->defer && !e->pipeline;
+    const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
     if (rc) return rc;
     if (defer && !e->strict) {
@@ -791,8 +746,7 @@ int mppi_solve_async(mppi_engine* e, void* stream)
         e->pending_idx = e->solve_idx;
         e->pending_stream = st;
     } else {
-        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr,
-                             true);
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr);
         if (rc) return rc;
     }
     e->solve_idx += 1;
@@ -931,10 +885,8 @@ int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const floa
         if (rc_) return rc_;
     }
     e->lambda = lambda;
-    if (sigma) {
+    if (sigma)
         for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
-        e->noise_ready_idx = -1;            // prefetched noise used the old sigma
-    }
     if (inv_s) for (int i = 0; i < e->A; ++i) e->inv_s[i] = inv_s[i];
     return MPPI_OK;
 }
@@ -943,7 +895,6 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     e->seed = seed;
-    e->noise_ready_idx = -1;
     return MPPI_OK;
 }
 
@@ -1004,11 +955,8 @@ int mppi_set_pipeline(mppi_engine* e, int on)
         int rc_ = settle(e);
         if (rc_) return rc_;
     }
-    if (on < 0 || on > 2) return fail(MPPI_EINVAL, "pipeline mode must be 0, 1 or 2");
-    e->pipeline = on == 1 ? 1 : 0;
+    if (on < 0 || on > 1) return fail(MPPI_EINVAL, "pipeline mode must be 0 or 1");
     e->defer = on == 0 ? 1 : 0;
-    e->noise_ready_idx = -1;
-    e->geom_ok = false;         // the occupancy-sized grid depends on the kernel variant
     return MPPI_OK;
 }
 
@@ -1020,10 +968,8 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = enqueue_rollout(e, st);      // (flushes a pending combine first)
     if (rc) return rc;
-    if (e->strict || e->pipeline) {
-        return enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial,
-                               true);
-    }
+    if (e->strict)
+        return enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial);
     // the same 256-thread combine the direct exchange runs, so that both transports add this
     // rank's partial in the same order (equal bits)
     mppi::CombineArgs ca;
@@ -1151,7 +1097,7 @@ int mppi_solve_exchange_async(mppi_engine* e, void* stream)
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    const bool defer = e->defer && !e->pipeline;
+    const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
     if (rc) return rc;
     if (defer && !e->strict) {
@@ -1164,8 +1110,7 @@ int mppi_solve_exchange_async(mppi_engine* e, void* stream)
         e->pending_idx = e->solve_idx;
         e->pending_stream = st;
     } else {
-        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr,
-                             true);
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr);
         if (rc) return rc;
     }
     e->xg_seq += 1;

@@ -133,83 +133,12 @@ k_rollout_stream(const RolloutArgs* __restrict__ gp, float* __restrict__ Eint,
 }
 
 // ------------------------------------------------------------------------------------------
-// Noise generation on its own (pipelined mode): one thread per Philox block, fully parallel,
-// every store a contiguous 1 KiB wave-instruction in the tile layout.  Draws exactly what
-// k_rollout_fused<.., SAMPLE = true> draws in place (same counter, same Box-Muller, same sigma).
-// In a solve sequence it does not run as a launch of its own: the blocks of the combine launch
-// that are not needed for combining (all but ~13) generate the NEXT solve's noise, which takes
-// the Philox work (~a third of the rollout) off the critical path without any cross-stream
-// synchronisation.  k_generate itself is launched only when nothing has been prefetched.
-// ------------------------------------------------------------------------------------------
-template <int A>
-__device__ __forceinline__ void generate_slots(const GenArgs& g, long long first, long long stride)
-{
-    // one thread per (trajectory, chunk) lane of the tile layout, looping over its nq blocks:
-    // no integer division on the path, every store is lane-contiguous (1 KiB per instruction)
-    const int C = 1 << g.logC;
-    const int nq = g.nq;
-    const float sig[4] = {g.sigma[0], g.sigma[1], g.sigma[2], g.sigma[3]};
-    for (long long gid = first; gid < g.n_lanes; gid += stride) {
-        const long long kloc = gid >> g.logC;
-        if (kloc >= g.K) continue;
-        const int c = (int)(gid & (C - 1));
-        const int lane = (int)(gid & 63);
-        const unsigned long long kglob = (unsigned long long)(g.k_offset + kloc);
-        float* dst = g.Eint + (((gid >> 6) * nq) * 64 + lane) * 4;
-        const int q_end = min(nq, g.NBT - c * nq);
-        const unsigned long long blk = g.blk_base + (unsigned long long)(c * nq);
-        // four independent Philox chains in flight per thread (the chain of ten dependent rounds
-        // is what limits a single one)
-        for (int q0 = 0; q0 < q_end; q0 += 4) {
-            uint4 r[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                r[j] = PhiloxAt::block(blk + (unsigned long long)(q0 + j), kglob, g.seed);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = q0 + j;
-                float z[4];
-                box_muller_hw(r[j].x, r[j].y, z[0], z[1]);
-                box_muller_hw(r[j].z, r[j].w, z[2], z[3]);
-                float e[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // axis of flat normal 4*(c*nq+q)+i; chunks start at a multiple of A
-                    const int a = (A == 1) ? 0 : (A == 2) ? (i & 1) : (A == 4) ? i : ((q * 4 + i) % 3);
-                    e[i] = sig[a] * z[i];
-                }
-                if (q < q_end)
-                    *reinterpret_cast<float4*>(dst + (size_t)q * 256) =
-                        make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
-    }
-}
-
-template <int A>
-__global__ void __launch_bounds__(256)
-k_generate(const GenArgs g)
-{
-    generate_slots<A>(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
-}
-
-// ------------------------------------------------------------------------------------------
 // Combine launches (the body lives in combine_impl.hpp).
 // ------------------------------------------------------------------------------------------
-template <int NR, int GA>    // NR row loads in flight per lane; GA = act_dim of the generation role, 0 = none
+template <int NR>    // NR row loads in flight per lane
 __global__ void __launch_bounds__(kCombineThreads)
-k_combine(const CombineArgs a, const GenArgs gen)
+k_combine(const CombineArgs a)
 {
-    // 1-D grid: the first n_cols * RS blocks combine, the rest (if any) draw the next solve's noise
-    const int n_comb = a.n_cols * a.RS;
-    if constexpr (GA > 0) {
-        if ((int)blockIdx.x >= n_comb) {
-            const long long gb = (long long)blockIdx.x - n_comb;
-            generate_slots<GA>(gen, gb * kCombineThreads + threadIdx.x,
-                               (long long)(gridDim.x - n_comb) * kCombineThreads);
-            return;
-        }
-    }
     __shared__ float smem[combine_smem_floats<kCombineThreads>()];
     combine_body<kCombineThreads, NR>(a, (int)blockIdx.x, carve_combine_smem<kCombineThreads>(smem));
 }
@@ -448,36 +377,6 @@ hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs
     }
 }
 
-hipError_t launch_generate(int A, const GenArgs& g, hipStream_t st)
-{
-    long long blocks = (g.n_lanes + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 65536) blocks = 65536;
-    const dim3 grid((unsigned)blocks), block(256);
-    switch (A) {
-        case 1: hipLaunchKernelGGL(k_generate<1>, grid, block, 0, st, g); break;
-        case 2: hipLaunchKernelGGL(k_generate<2>, grid, block, 0, st, g); break;
-        case 3: hipLaunchKernelGGL(k_generate<3>, grid, block, 0, st, g); break;
-        case 4: hipLaunchKernelGGL(k_generate<4>, grid, block, 0, st, g); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-template <int NR>
-static void launch_combine_nr(int gen_A, const dim3& grid, const CombineArgs& a, const GenArgs& g,
-                              hipStream_t st, LaunchTiming tm)
-{
-    const dim3 block(kCombineThreads);
-    switch (gen_A) {
-        case 1: MPPI_LAUNCH((k_combine<NR, 1>), grid, block, 0, st, tm, a, g); break;
-        case 2: MPPI_LAUNCH((k_combine<NR, 2>), grid, block, 0, st, tm, a, g); break;
-        case 3: MPPI_LAUNCH((k_combine<NR, 3>), grid, block, 0, st, tm, a, g); break;
-        case 4: MPPI_LAUNCH((k_combine<NR, 4>), grid, block, 0, st, tm, a, g); break;
-        default: MPPI_LAUNCH((k_combine<NR, 0>), grid, block, 0, st, tm, a, g); break;
-    }
-}
-
 hipError_t launch_finish_gathered(const CombineArgs& a, const float* gathered, int G,
                                   hipStream_t st, LaunchTiming tm)
 {
@@ -487,8 +386,7 @@ hipError_t launch_finish_gathered(const CombineArgs& a, const float* gathered, i
     return hipGetLastError();
 }
 
-hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming tm,
-                          const GenArgs* gen, int gen_A)
+hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming tm)
 {
     CombineArgs a = a_in;
     const int cols = (a.TA + kCombineCols - 1) / kCombineCols;
@@ -500,22 +398,11 @@ hipError_t launch_combine(const CombineArgs& a_in, hipStream_t st, LaunchTiming 
     if (rs > kMaxRowSplits) rs = kMaxRowSplits;
     a.n_cols = cols;
     a.RS = rs;
-    GenArgs g;
-    memset(&g, 0, sizeof g);
-    int n_gen = 0;
-    if (gen && gen_A >= 1 && gen_A <= 4 && gen->n_lanes > 0) {
-        g = *gen;
-        // enough 1024-thread blocks to fill the chip twice, no more than there are lanes
-        long long want = (g.n_lanes + kCombineThreads - 1) / kCombineThreads;
-        n_gen = (int)(want < 512 ? want : 512);
-    } else {
-        gen_A = 0;
-    }
-    const dim3 grid((unsigned)(cols * rs + n_gen));
+    const dim3 grid((unsigned)(cols * rs)), block(kCombineThreads);
     const int rows_per_wave = ((a.n_parts + rs - 1) / rs + kRowGroups - 1) / kRowGroups;   // per row group
-    if (rows_per_wave <= 8) launch_combine_nr<8>(gen_A, grid, a, g, st, tm);
-    else if (rows_per_wave <= 20) launch_combine_nr<20>(gen_A, grid, a, g, st, tm);
-    else launch_combine_nr<40>(gen_A, grid, a, g, st, tm);
+    if (rows_per_wave <= 8) MPPI_LAUNCH((k_combine<8>), grid, block, 0, st, tm, a);
+    else if (rows_per_wave <= 20) MPPI_LAUNCH((k_combine<20>), grid, block, 0, st, tm, a);
+    else MPPI_LAUNCH((k_combine<40>), grid, block, 0, st, tm, a);
     return hipGetLastError();
 }
 

@@ -234,25 +234,10 @@ int combine_small_prepare(CombineArgs& a);
 size_t combine_small_lds_bytes();
 hipError_t launch_combine_small(const CombineArgs& a_prepared, hipStream_t st,
                                 LaunchTiming tm = LaunchTiming());
-// Noise generation outside the rollout (pipelined mode): fills one tile-layout buffer with the
-// noise of one solve; identical values to what the fused kernel draws in place.
-struct GenArgs {
-    float* Eint;
-    unsigned long long seed;
-    unsigned long long blk_base;   // solve_idx * NBT
-    long long k_offset;
-    long long n_lanes;             // lanes of the tile layout = tiles * 64 (each draws nq blocks)
-    int K, NBT, logC, nq;
-    float sigma[4];
-};
-hipError_t launch_generate(int A, const GenArgs& g, hipStream_t st);
-
 hipError_t launch_rollout_stream(int A, bool sample, int grid, const RolloutArgs& a,
                                  hipStream_t st, LaunchTiming tm = LaunchTiming());
-// gen != nullptr: the launch also carries blocks that draw the noise described by *gen
-// (act_dim gen_A) -- the next solve's noise, generated underneath this solve's combine.
-hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming(),
-                          const GenArgs* gen = nullptr, int gen_A = 0);
+// The combine in 1024-thread blocks with ticketed row splits (eager mode).
+hipError_t launch_combine(const CombineArgs& a, hipStream_t st, LaunchTiming tm = LaunchTiming());
 
 // Final combine of G gathered rank partials ([G][TA+2] floats: beta_g, S_g, N_g[TA]) in rank
 // order -- the same arithmetic the direct exchange applies, so both transports give equal bits.

@@ -2,7 +2,7 @@
 # usage: tools/modes.sh <tag> <bench args...>: us/solve in the three enqueue modes + blocking get_act
 tag=$1; shift
 mkdir -p gpurun_out
-for cfg in "0" "2" "0 --blocking" "2 --blocking"; do
+for cfg in "0" "1" "0 --blocking" "1 --blocking"; do
   name=$(echo $cfg | tr -d ' -')
   timeout -k 10 120 python bench.py --no-cpu-baseline --pipeline $cfg "$@" > gpurun_out/modes_${tag}_$name.json 2>gpurun_out/modes_${tag}_$name.err || { tail -3 gpurun_out/modes_${tag}_$name.err; exit 1; }
   python3 -c "
