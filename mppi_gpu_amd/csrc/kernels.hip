@@ -287,8 +287,9 @@ int rollout_pick_ng_template(int A, int ng)
 }
 
 size_t rollout_lds_bytes(int NBTp, int TAp)
-{   // u and lambda*inv_s*u blocks, 4 per-wave rows + the running row, scratch
-    return (size_t)NBTp * 32 + (size_t)(5 * TAp + 8) * sizeof(float);
+{   // u and lambda*inv_s*u blocks, 4 per-wave rows + the running row, scratch, and one private
+    // snapshot slot per thread (cost so far + state at the last step: 1 + 2*4 floats at most)
+    return (size_t)NBTp * 32 + (size_t)(5 * TAp + 8 + 9 * kRolloutThreads) * sizeof(float);
 }
 
 template <int A>

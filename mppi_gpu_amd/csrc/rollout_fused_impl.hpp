@@ -70,6 +70,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
     float* wsum = reinterpret_cast<float*>(uclds + NBTp);        // [4][TAp]
     float* nrun = wsum + 4 * TAp;                                // [TAp]
     float* misc = nrun + TAp;                                    // [8]
+    float* snap = misc + 8 + threadIdx.x;                        // [1 + 2A][256]: this thread's slot
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -295,11 +296,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         // ---- pass 2: dynamics + stage cost over the own chunk (src/point_mass_gpu.cu:97-107,
         //      src/cost.cu:42-55).  No per-step masking: the chunk that holds step T-1 takes a
         //      snapshot (cost so far, state) at the wave-uniform step n_last and uses that. ----
-        float cpart = 0.0f, cT = 0.0f;
-        float pT[A], vT[A];
+        float cpart = 0.0f;
         if constexpr (!EXACT) asm volatile("" : "+s"(ngs));
-#pragma unroll
-        for (int i = 0; i < A; ++i) { pT[i] = 0.f; vT[i] = 0.f; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             if (gi < ngs) {
@@ -335,16 +333,29 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         r = fmaf(d * P.w[A + i], d, r);
                     }
                     cpart += r;
-                    if (sl + 1 == n_last) {                  // wave-uniform: keep it a scalar
-                        asm volatile("" ::: "memory");       // branch (hipcc would if-convert it
-                        cT = cpart;                          // into 2A+1 v_cndmask per step)
+                    if (sl + 1 == n_last) {
+                        // wave-uniform scalar branch, taken at one step per tile: the snapshot
+                        // goes through the thread's LDS slot.  (Kept in registers it becomes
+                        // 2A+1 loop-carried values that hipcc copies at EVERY step: 70 v_mov per
+                        // tile at act_dim 2, 6.6 % of the kernel's VALU instructions.)
+                        snap[0] = cpart;
 #pragma unroll
-                        for (int i = 0; i < A; ++i) { pT[i] = p[i]; vT[i] = v[i]; }
+                        for (int i = 0; i < A; ++i) {
+                            snap[(1 + i) * kRolloutThreads] = p[i];
+                            snap[(1 + A + i) * kRolloutThreads] = v[i];
+                        }
                     }
                 }
             }
         }
         {
+            const float cT = snap[0];
+            float pT[A], vT[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                pT[i] = snap[(1 + i) * kRolloutThreads];
+                vT[i] = snap[(1 + A + i) * kRolloutThreads];
+            }
             float fc = 0.0f;    // Cost::final_cost (src/cost.cu:57-64) on the state after step T-1
 #pragma unroll
             for (int i = 0; i < A; ++i) {
