@@ -225,8 +225,8 @@ def main():
             # for reference, outside the timed region: the two kernels on their own (eager mode,
             # one rollout launch + one combine launch per solve)
             m.set_pipeline(1)
-            m.set_profiling(1)
-            for _ in range(64):
+            m.set_profiling(8)
+            for _ in range(512):
                 m.solve_async()
             m.sync_act()
             r_ms, _ = m.kernel_ms(0)
