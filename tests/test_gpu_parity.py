@@ -274,6 +274,55 @@ def test_deferred_combine_interleaved_with_everything_else(gpu):
         assert np.abs(x - y).max() <= 1e-4 * scale      # chains of up to 9 solves, see above
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_call_sequences_do_not_depend_on_how_solves_are_enqueued(gpu, seed):
+    """Random shapes (tiny horizons and batches included) and random call sequences: the same
+    sequence with a synchronisation forced after every solve (every combine flushed on its own)
+    must give the bits of the free-running sequence (combines riding wherever they can), and the
+    injected-noise mode must go through the same machinery."""
+    rng = np.random.default_rng(1000 + seed)
+    A = int(rng.integers(1, 5))
+    T = int(rng.choice([1, 2, 3, 5, 17, 50, 200]))
+    K = int(rng.choice([1, 3, 64, 257, 2000, 9000]))
+    c = ol.make_case(A, K, T, seed=200 + seed, u_scale=0.05)
+    inject = bool(rng.integers(0, 2))
+    ops = [str(rng.choice(["solve", "solve", "solve", "set_x", "get_u", "params", "get_act"]))
+           for _ in range(14)]
+    xs = [(c["x0"] * np.float32(rng.uniform(0.5, 1.5))).astype(np.float32) for _ in ops]
+    lams = [float(rng.uniform(0.5, 3.0)) for _ in ops]
+
+    def run(force_sync):
+        with _model(gpu, A, K, T, c) as m:
+            m.set_seed(40 + seed)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            if inject:
+                m.set_noise(c["E"])
+            log = []
+            for i, op in enumerate(ops):
+                if op == "solve":
+                    m.solve_async()
+                    if force_sync:
+                        m.sync_act()
+                elif op == "set_x":
+                    m.set_x(xs[i])
+                elif op == "get_u":
+                    log.append(m.get_u())
+                elif op == "params":
+                    m.set_params(lams[i], None, None)
+                else:
+                    log.append(m.get_act())
+            log.append(m.sync_act() if any(o in ("solve", "get_act") for o in ops) else np.zeros(A))
+            log.append(m.get_u())
+            return log
+
+    free, forced = run(False), run(True)
+    assert len(free) == len(forced)
+    for a, b in zip(free, forced):
+        assert np.array_equal(a, b), (A, K, T, inject, ops)
+    assert all(np.all(np.isfinite(a)) for a in free)
+
+
 def test_persistent_grid_and_rescale_path(gpu):
     """max_blocks << tiles forces every block through several tile groups, i.e. through the
     running-minimum rescale branch; costs are spread so that block minima differ a lot."""
