@@ -64,7 +64,9 @@ int mppi_get_x(mppi_engine* e, float* x0);
 
 /* PointMassModel::get_act(next_act), src/point_mass.cu:129-203: one full solve
  * (sample + rollout + cost, beta, nabla, weighted update), returns U[0,:] of the UPDATED
- * sequence in next_act[A], then shifts U left by one step.  Blocking, like the reference. */
+ * sequence in next_act[A], then shifts U left by one step.  Blocking, like the reference: it
+ * returns when the action has arrived in host memory (the combine kernel writes it into pinned
+ * words the call polls); later calls on the engine are ordered behind the solve as usual. */
 int mppi_get_act(mppi_engine* e, float* next_act);
 
 /* PointMassModel::get_u(u), src/point_mass.cu:488-491: current U[T*A] */
@@ -159,8 +161,8 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
  * polls its own inbox for the other ranks' words and applies the update -- bit-identical to
  * mppi_solve_local_async + all-gather + mppi_solve_finish_async.  In pipeline mode 0 that launch
  * is deferred like the single-GPU combine: with solves enqueued back to back it rides in the next
- * solve's rollout launch, and the peers' words arrive while this rank draws the next noise.  All ranks must make the same
- * sequence of exchange calls; a rank that waits longer than the time-out (default 5 s) gives up,
+ * solve's rollout launch, and the peers' words arrive while this rank draws the next noise.
+ * All ranks must make the same sequence of exchange calls; a rank that waits longer than the time-out (default 5 s) gives up,
  * and the next mppi_sync_act / mppi_get_act returns MPPI_ESTATE.  world <= 64. */
 int mppi_xchg_handle_bytes(void);
 int mppi_xchg_open(mppi_engine* e, int rank, int world, void* handle_out, void** inbox_out);
@@ -172,11 +174,12 @@ int mppi_xchg_close(mppi_engine* e);
 /* ---- measurement ------------------------------------------------------------------- */
 
 /* every > 0: each `every`-th solve records HIP events around its kernels on the launch stream
- * (an event pair costs a few microseconds of stream time, so sparse sampling keeps the timed
+ * (a stamped dispatch runs about a microsecond longer, so sparse sampling keeps the timed
  * region honest); 0 switches recording off. */
 int mppi_set_profiling(mppi_engine* e, int every);
-/* Average duration in ms of kernel `which` (0 = rollout, 1 = combine) over the solves since
- * profiling was switched on; *n_out = number of launches averaged. Synchronises. */
+/* Average duration in ms of the sampled launches of kind `which` (0 = rollout launches, including
+ * those that carry a combine; 1 = stand-alone combine launches) since profiling was switched
+ * on; *n_out = number of launches averaged. Synchronises. */
 int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);
 /* Launch geometry actually in use: chunks, blocks per chunk (nq), grid, block, strict. */
 int mppi_get_geometry(mppi_engine* e, int out[5]);

@@ -419,7 +419,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
 
 // Occupancy target: the kernel is VALU-issue / latency bound, so 4 waves per SIMD (<= 128 VGPRs)
 // where the register-resident noise leaves room; forcing it on larger chunks spills
-// (measured: -35 %), so those keep hipcc's own allocation.
+// (measured: -35 %; three waves for 48 resident normals: 23 spilled registers, -25 %), so those
+// keep hipcc's own allocation.
 template <int A, int NG>
 constexpr int fused_min_waves()
 {
