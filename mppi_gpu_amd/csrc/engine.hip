@@ -289,6 +289,8 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.fin_tag = e->d_slab_tag + (size_t)mppi::kMaxSmallSplits * e->TA;
     a.err_dev = e->d_err;
     a.err_host = e->h_err_dev;
+    // a riding exchange may itself wait for a late peer: the rollout blocks outwait it
+    a.ride_timeout_ticks = (unsigned long long)((2.0 + (e->xg_connected ? e->xg_timeout_s : 0.0)) * 1e8);
     a.U = e->d_U;
     a.Eint = e->d_Eint;
     a.cost = e->d_cost;
@@ -431,8 +433,8 @@ int check_watchdog(mppi_engine_t* e)
     if (code == 1)
         return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
                     "solve %llu", e->xg_timeout_s, e->solve_idx);
-    return fail(MPPI_ESTATE, "device watchdog %d: a block waited 2 s for the combine riding in "
-                "its own launch", code);
+    return fail(MPPI_ESTATE, "device watchdog %d: a block gave up waiting for the combine that "
+                "rides in its own launch", code);
 }
 
 // everything enqueued by this engine has run, nothing is pending

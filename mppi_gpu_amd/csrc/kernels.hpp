@@ -68,6 +68,7 @@ struct RolloutArgs {
     const unsigned long long* fin_tag;
     int* err_dev;
     int* err_host;
+    unsigned long long ride_timeout_ticks;   // 100 MHz ticks a rollout block waits for the controls
 };
 
 // What the first instructions of the fused rollout need, passed BY VALUE as kernel arguments

@@ -170,7 +170,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                 // DeferredCombine), one value per thread and sweep, polling what is not there
                 // yet (bounded).
                 const unsigned long long t0 = wall_clock64();
-                const unsigned long long limit = 200000000ull;        // 2 s at 100 MHz
+                const unsigned long long limit = g.ride_timeout_ticks;
                 bool timed_out = false;
                 float* uflat = reinterpret_cast<float*>(ulds);
                 float* ucflat = reinterpret_cast<float*>(uclds);
