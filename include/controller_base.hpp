@@ -36,6 +36,10 @@ public:
     void setParams(float lambda, const float* sigma, const float* inv_s);  // null keeps value
     void setSeed(unsigned long long seed);      // restarts the noise stream
     void setNoise(const float* E);              // injected noise [k][tau][aDim]; null = sample
+    // worker threads for the sample loops (default 1 = the serial controller).  Samples are
+    // independent and every control value is still summed over the samples in order, so the
+    // results do not depend on the number of threads.
+    void setThreads(int n);
 
     const std::vector<float>& actions() const { return mU; }
     const std::vector<float>& costs() const { return mCost; }
@@ -46,6 +50,7 @@ public:
 
 private:
     int mK, mTau, mSDim, mADim;
+    int mThreads;
     float mDt, mLambda;
     unsigned long long mSeed, mSolve;
     bool mInjected;

@@ -199,6 +199,8 @@ int mppi_cpu_set_params(mppi_cpu_controller* c, float lambda, const float* sigma
                         const float* inv_s);
 int mppi_cpu_set_seed(mppi_cpu_controller* c, unsigned long long seed);
 int mppi_cpu_set_noise(mppi_cpu_controller* c, const float* noise);
+/* worker threads for the sample loops (default 1); results do not depend on the count */
+int mppi_cpu_set_threads(mppi_cpu_controller* c, int n);
 int mppi_cpu_next(mppi_cpu_controller* c, const float* x, float* act);
 int mppi_cpu_get(mppi_cpu_controller* c, float* u, float* noise, float* cost, float* beta,
                  float* nabla, float* weight);

@@ -275,6 +275,10 @@ class ControllerBase:
         check(self._lib.mppi_cpu_set_params(self._h, float(lam), _fp(s) if s is not None else null,
                                             _fp(i) if i is not None else null))
 
+    def setThreads(self, n):
+        """Worker threads for the sample loops (default 1); results do not depend on the count."""
+        check(self._lib.mppi_cpu_set_threads(self._h, int(n)))
+
     def setSeed(self, seed):
         check(self._lib.mppi_cpu_set_seed(self._h, int(seed)))
 

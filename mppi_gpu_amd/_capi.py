@@ -58,6 +58,7 @@ SIGNATURES = {
     "mppi_cpu_set_params": (C.c_int, [C.c_void_p, C.c_float, c_float_p, c_float_p]),
     "mppi_cpu_set_seed": (C.c_int, [C.c_void_p, C.c_ulonglong]),
     "mppi_cpu_set_noise": (C.c_int, [C.c_void_p, c_float_p]),
+    "mppi_cpu_set_threads": (C.c_int, [C.c_void_p, C.c_int]),
     "mppi_cpu_next": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
     "mppi_cpu_get": (C.c_int, [C.c_void_p] + [c_float_p] * 6),
     "mppi_device_count": (C.c_int, []),

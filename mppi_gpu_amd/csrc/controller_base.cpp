@@ -1,4 +1,4 @@
-// controller_base.cpp -- serial CPU MPPI (see include/controller_base.hpp).
+// controller_base.cpp -- CPU MPPI, serial by default (see include/controller_base.hpp).
 // Stage numbers refer to the reference's intended pipeline, src/controller_base.cpp:61-80, and
 // to the GPU path it mirrors, src/point_mass.cu:129-203.
 #include "../../include/controller_base.hpp"
@@ -10,8 +10,27 @@
 
 #include <cmath>
 #include <cstdio>
+#include <functional>
+#include <thread>
 
 namespace {
+
+// fn(begin, end) over [0, n) in `threads` contiguous pieces (the caller's thread takes the first)
+void parallel_ranges(int n, int threads, const std::function<void(int, int)>& fn)
+{
+    if (threads <= 1 || n < 2 * threads) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int per = (n + threads - 1) / threads;
+    for (int t = 1; t < threads; ++t) {
+        const int b = t * per, e = b + per < n ? b + per : n;
+        if (b < e) pool.emplace_back(fn, b, e);
+    }
+    fn(0, per < n ? per : n);
+    for (std::thread& th : pool) th.join();
+}
 
 // Box-Muller of the engine (kernels: box_muller_hw), evaluated with libm on the host.
 void box_muller_host(unsigned int x, unsigned int y, float* z0, float* z1)
@@ -29,7 +48,7 @@ void box_muller_host(unsigned int x, unsigned int y, float* z0, float* z1)
 
 ControllerBase::ControllerBase(const int k, const int tau, const float dt, const int sDim,
                                const int aDim)
-    : mK(k), mTau(tau), mSDim(sDim), mADim(aDim), mDt(dt), mLambda(1.0f), mSeed(0), mSolve(0),
+    : mK(k), mTau(tau), mSDim(sDim), mADim(aDim), mThreads(1), mDt(dt), mLambda(1.0f), mSeed(0), mSolve(0),
       mInjected(false), mBeta(0.0f), mNabla(0.0f)
 {
     mU.assign((size_t)tau * aDim, 0.0f);
@@ -76,6 +95,8 @@ void ControllerBase::setSeed(unsigned long long seed)
     mSolve = 0;
 }
 
+void ControllerBase::setThreads(int n) { mThreads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+
 void ControllerBase::setNoise(const float* E)
 {
     mInjected = E != nullptr;
@@ -88,7 +109,8 @@ void ControllerBase::sampleNoise()
 {
     const int TA = mTau * mADim;
     const unsigned long long NBT = (unsigned long long)((TA + 3) / 4);
-    for (int k = 0; k < mK; ++k) {
+    parallel_ranges(mK, mThreads, [&](int k0, int k1) {
+    for (int k = k0; k < k1; ++k) {
         for (unsigned long long b = 0; b < NBT; ++b) {
             rocrand_state_philox4x32_10 st;
             rocrand_init(mSeed, (unsigned long long)k, 4ull * (mSolve * NBT + b), &st);
@@ -102,6 +124,7 @@ void ControllerBase::sampleNoise()
             }
         }
     }
+    });
 }
 
 void ControllerBase::next(const float* x, float* act)
@@ -109,11 +132,19 @@ void ControllerBase::next(const float* x, float* act)
     const int TA = mTau * mADim;
     if (!mInjected) sampleNoise();
 
-    // stage 2 -- simulate every sample, one after the other
+    // stage 2 -- simulate every sample, one after the other (per worker: its own state trace)
     std::vector<float> x0(x, x + mSDim);
-    for (int k = 0; k < mK; ++k) {
+    parallel_ranges(mK, mThreads, [&](int k0, int k1) {
+    std::vector<float> trace_local;
+    float* X = mX.data();
+    if (k0 != 0) {
+        trace_local.assign(mX.size(), 0.0f);
+        X = trace_local.data();
+    }
+    std::vector<float> x0w(x0);
+    for (int k = k0; k < k1; ++k) {
         PointMassModelGpu sim;
-        sim.init(mX.data(), x0.data(), mU.data(), &mE[(size_t)k * TA], mTau, mXGain, mSDim, mUGain,
+        sim.init(X, x0w.data(), mU.data(), &mE[(size_t)k * TA], mTau, mXGain, mSDim, mUGain,
                  mADim, mW.data(), mGoal.data(), mLambda, k);
         // the per-sample type fixes inv_s = 1 like the reference; honour a custom inv_s by
         // evaluating the control term here when it differs
@@ -125,12 +156,13 @@ void ControllerBase::next(const float* x, float* act)
             Cost stage(mW.data(), mSDim, mGoal.data(), mSDim, mLambda, mInvS.data(), mADim);
             c = 0.0f;
             for (int t = 0; t < mTau; ++t)
-                c += stage.step_cost(&mX[(size_t)(t + 1) * mSDim], &mU[(size_t)t * mADim],
+                c += stage.step_cost(&X[(size_t)(t + 1) * mSDim], &mU[(size_t)t * mADim],
                                      &mE[(size_t)k * TA + (size_t)t * mADim], k, t);
-            c += stage.final_cost(&mX[(size_t)mTau * mSDim], k);
+            c += stage.final_cost(&X[(size_t)mTau * mSDim], k);
         }
         mCost[k] = c;
     }
+    });
 
     // stage 3 -- beta = min cost (numerical stability of the exponentials)
     float beta = INFINITY;
@@ -149,9 +181,13 @@ void ControllerBase::next(const float* x, float* act)
         mWeights[k] = (float)(1.0 / (double)nabla * (double)mWeights[k]);
 
     // stage 7 -- weighted mean of the noise, U += sum_k w_k E_k (double accumulators)
+    // (workers split the control values, not the samples: every value is summed over k in order)
     std::vector<double> acc(TA, 0.0);
-    for (int k = 0; k < mK; ++k)
-        for (int n = 0; n < TA; ++n) acc[n] += (double)mWeights[k] * (double)mE[(size_t)k * TA + n];
+    parallel_ranges(TA, mThreads, [&](int n0, int n1) {
+        for (int k = 0; k < mK; ++k)
+            for (int n = n0; n < n1; ++n)
+                acc[n] += (double)mWeights[k] * (double)mE[(size_t)k * TA + n];
+    });
     for (int n = 0; n < TA; ++n) mU[n] = (float)((double)mU[n] + acc[n]);
 
     // action out, then shift with the last step repeated (reference src/point_mass.cu:195-199)
@@ -207,6 +243,12 @@ int mppi_cpu_set_seed(mppi_cpu_controller* c, unsigned long long seed)
 {
     if (!c) return MPPI_EINVAL;
     reinterpret_cast<ControllerBase*>(c)->setSeed(seed);
+    return MPPI_OK;
+}
+int mppi_cpu_set_threads(mppi_cpu_controller* c, int n)
+{
+    if (!c || n < 1) return MPPI_EINVAL;
+    reinterpret_cast<ControllerBase*>(c)->setThreads(n);
     return MPPI_OK;
 }
 int mppi_cpu_set_noise(mppi_cpu_controller* c, const float* noise)

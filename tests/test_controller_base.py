@@ -62,3 +62,30 @@ def test_controller_base_inv_s_and_lambda():
     st = cb.state()
     assert np.array_equal(st["cost"], ref["cost"])
     np.testing.assert_allclose(st["u"], ref["U"], rtol=0, atol=1e-7)
+
+
+def test_controller_base_threads_do_not_change_results():
+    """setThreads: the sample loops run on worker threads; samples are independent and every
+    control value is still summed over the samples in order, so 1, 3 and 8 threads must give
+    identical bits (sampling mode, several iterations, state fed back)."""
+    from mppi_gpu_amd import ControllerBase
+    A, K, T = 2, 500, 40
+    c = ol.make_case(A, K, T, seed=77)
+    runs = []
+    for threads in (1, 3, 8):
+        ctl = ControllerBase(K, T, float(c["dt"]), 2 * A, A)
+        ctl.setThreads(threads)
+        ctl.setSeed(5)
+        ctl.setActions(c["U"])
+        ctl.setCost(c["goal"], c["w"])
+        x = c["x0"].copy()
+        acts = []
+        for it in range(3):
+            acts.append(ctl.next(x).copy())
+            x = (x + np.float32(0.01)).astype(np.float32)
+        st = ctl.state()
+        runs.append((np.stack(acts), st["u"].copy(), st["cost"].copy(), st["e"].copy()))
+        ctl.close()
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert np.array_equal(a, b)
