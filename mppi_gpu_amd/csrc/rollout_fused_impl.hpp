@@ -176,23 +176,46 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                 float* ucflat = reinterpret_cast<float*>(uclds);
                 const unsigned long long* fin_p = g.fin_tag;
                 const unsigned int tag_want = d.c.tag;
-                for (int idx = threadIdx.x; idx < NBTp * 4; idx += kRolloutThreads) {
-                    float unew = 0.0f;
-                    if (idx < TA) {
-                        const int n = (idx < TA - A) ? idx + A : idx;  // shift; last step repeats
-                        for (;;) {
-                            const unsigned long long w = __hip_atomic_load(
-                                fin_p + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned int)(w >> 32) == tag_want) {
-                                unew = __uint_as_float((unsigned int)w);
-                                break;
+                constexpr int kBatch = 4;      // words in flight per thread: one round trip, not four
+                for (int base = threadIdx.x; base < NBTp * 4; base += kBatch * kRolloutThreads) {
+                    float unew[kBatch];
+                    bool have[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        unew[j] = 0.0f;
+                        have[j] = base + j * kRolloutThreads >= TA;     // padding: nothing to fetch
+                    }
+                    for (;;) {
+                        unsigned long long w[kBatch];
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            const int idx = base + j * kRolloutThreads;
+                            const int n = (idx < TA - A) ? idx + A : idx;  // shift; last step repeats
+                            w[j] = have[j] ? 0ull
+                                           : __hip_atomic_load(fin_p + n, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        bool all = true;
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            if (!have[j] && (unsigned int)(w[j] >> 32) == tag_want) {
+                                unew[j] = __uint_as_float((unsigned int)w[j]);
+                                have[j] = true;
                             }
-                            if (wall_clock64() - t0 > limit) { timed_out = true; break; }
-                            __builtin_amdgcn_s_sleep(4);
+                            all = all && have[j];
+                        }
+                        if (all) break;
+                        if (wall_clock64() - t0 > limit) { timed_out = true; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        const int idx = base + j * kRolloutThreads;
+                        if (idx < NBTp * 4) {
+                            uflat[idx] = unew[j];
+                            ucflat[idx] = lambda * (unew[j] * g.inv_s[idx % A]);
                         }
                     }
-                    uflat[idx] = unew;
-                    ucflat[idx] = lambda * (unew * g.inv_s[idx % A]);
                 }
                 if (timed_out) {     // device watchdog word, reported by the next mppi_sync_act
                     *g.err_dev = 2;

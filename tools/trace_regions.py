@@ -35,7 +35,7 @@ if ride:
         m.solve_async()                              # the last launch carried a combine
     m.sync_act()
     import math
-    rs = max(1, math.ceil(grid / 320))
+    rs = min(8, max(1, math.ceil(grid / 320)))
     nb = math.ceil(T * A / 16) * rs
 else:
     m.solve_async(); m.sync_act()
