@@ -465,7 +465,10 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         }();
         const bool short_launch = (long long)e->n_tileblk <= (long long)max_tiles * e->grid;
         if (!carry || e->strict || e->pending_stream != st || !short_launch) {
+            const hipStream_t was = e->pending_stream;
             if ((rc = flush_pending(e))) return rc;
+            // a solve that moves to another stream must still see the controls of the last one
+            if (was != st) HIPCHK(hipStreamSynchronize(was));
         }
     }
     e->last_stream = st;
@@ -1083,7 +1086,10 @@ int mppi_xchg_set_timeout(mppi_engine* e, double seconds)
 int mppi_xchg_close(mppi_engine* e)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    e->pending = false;         // an exchange nobody waited for
+    if (e->pending && e->pending_mode == 2)
+        e->pending = false;     // an exchange nobody waited for cannot complete without its inbox
+    else
+        (void)flush_pending(e);
     if (e->last_stream) (void)hipStreamSynchronize(e->last_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->xg_opened) (void)hipIpcCloseMemHandle(p);
