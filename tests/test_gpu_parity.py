@@ -275,6 +275,28 @@ def test_deferred_combine_interleaved_with_everything_else(gpu):
 
 
 @pytest.mark.gpu
+def test_long_riding_chain_equals_flushed_chain(gpu):
+    """3 000 solves at the bench shape, enqueued back to back (every combine rides and hands the
+    controls over through tagged words while the next rollout is already running) against the
+    same chain with every combine launched on its own: a single stale or torn hand-over would
+    change the next solve and, through the chain, the final bits.  (tools/soak.py runs 1e5.)"""
+    A, K, T, n = 2, 10000, 200, 3000
+    c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)
+    res = []
+    for blocking in (False, True):
+        with _model(gpu, A, K, T, c) as m:
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            for _ in range(n):
+                if blocking:
+                    m.get_act()
+                else:
+                    m.solve_async()
+            res.append((m.sync_act().copy(), m.get_u().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.all(np.isfinite(res[0][1]))
+
+
+@pytest.mark.gpu
 def test_solves_that_change_stream_stay_ordered(gpu):
     """A held-back combine belongs to the stream of its solve; a next solve on ANOTHER stream must
     still start from its controls (flush + wait on the old stream), so hopping between two caller
