@@ -739,6 +739,7 @@ int mppi_get_x(mppi_engine* e, float* x0)
 int mppi_solve_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (e->h_err && *e->h_err) return check_watchdog(e);   // fail fast after a device time-out
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
@@ -1104,6 +1105,7 @@ int mppi_solve_exchange_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
+    if (e->h_err && *e->h_err) return check_watchdog(e);   // fail fast after a device time-out
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
