@@ -173,13 +173,13 @@ int mppi_xchg_close(mppi_engine* e);
 
 /* ---- measurement ------------------------------------------------------------------- */
 
-/* every > 0: each `every`-th solve records HIP events around its kernels on the launch stream
- * (a stamped dispatch runs about a microsecond longer, so sparse sampling keeps the timed
- * region honest); 0 switches recording off. */
+/* every > 0: each `every`-th solve and the solve after it record HIP events around their kernels
+ * on the launch stream (sparse, so that the timed region stays honest; in pairs, because a stamp
+ * behind an unstamped dispatch also covers that dispatch's tail); 0 switches recording off. */
 int mppi_set_profiling(mppi_engine* e, int every);
 /* Average duration in ms of the sampled launches of kind `which` (0 = rollout launches, including
- * those that carry a combine; 1 = stand-alone combine launches) since profiling was switched
- * on; *n_out = number of launches averaged. Synchronises. */
+ * those that carry a combine: the second of each stamped pair; 1 = stand-alone combine launches)
+ * since profiling was switched on; *n_out = number of launches averaged. Synchronises. */
 int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);
 /* Launch geometry actually in use: chunks, blocks per chunk (nq), grid, block, strict. */
 int mppi_get_geometry(mppi_engine* e, int out[5]);

@@ -134,9 +134,12 @@ struct mppi_engine {
     double xg_timeout_s = 5.0;
 
     // profiling
-    int prof = 0;                   // 0 = off, n = record every n-th solve
+    int prof = 0;                   // 0 = off, n = record every n-th solve (and the one after it)
     bool prof_now = false;
+    bool prof_prev = false;         // the previous rollout launch was stamped too
     unsigned long long prof_count = 0;
+    std::vector<char> ev_clean;     // per rollout pair: its predecessor was stamped as well, so the
+                                    // stamp covers this dispatch alone (see mppi_kernel_ms)
     std::vector<hipEvent_t> ev[2];  // start/stop pairs: [0] rollout launches, [1] combine launches
     size_t ev_used[2] = {0, 0};
 
@@ -504,9 +507,14 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         dc.n_blocks = dc.c.n_cols * dc.c.RS;
         e->pending = false;
     }
-    e->prof_now = e->prof > 0 && (e->prof_count++ % (unsigned long long)e->prof) == 0;
+    {   // every n-th solve AND its successor: a stamp is clean only behind a stamped predecessor
+        const unsigned long long ph = e->prof > 0 ? e->prof_count++ % (unsigned long long)e->prof : 2;
+        e->prof_now = e->prof > 0 && (ph == 0 || (ph == 1 && e->prof > 2));
+    }
     mppi::LaunchTiming tm;
     if ((rc = prof_pair(e, tm, 0))) return rc;
+    if (tm.start) e->ev_clean.push_back(e->prof_prev ? 1 : 0);
+    e->prof_prev = tm.start != nullptr;
     const bool sample_in_kernel = !e->injected;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
@@ -1136,6 +1144,8 @@ int mppi_set_profiling(mppi_engine* e, int on)
     e->prof = on > 0 ? on : 0;
     e->prof_now = false;
     e->prof_count = 0;
+    e->prof_prev = false;
+    e->ev_clean.clear();
     e->ev_used[0] = e->ev_used[1] = 0;
     return MPPI_OK;
 }
@@ -1145,9 +1155,17 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out)
     if (!e || !avg_ms || !n_out) return fail(MPPI_EINVAL, "null argument");
     if (which < 0 || which > 1) return fail(MPPI_EINVAL, "which must be 0 or 1");
     HIPCHK(hipDeviceSynchronize());
+    // A stamp behind an UNstamped dispatch also covers the wait for that dispatch's tail
+    // (~1.5 us); rollout launches are therefore stamped in pairs and only the second of a pair --
+    // what the profiler, which stamps everything, would report -- is averaged when there is one.
+    bool have_clean = false;
+    if (which == 0)
+        for (size_t p = 0; p < e->ev_clean.size() && 2 * p + 2 <= e->ev_used[0]; ++p)
+            have_clean = have_clean || e->ev_clean[p];
     double tot = 0.0;
     int n = 0;
     for (size_t i = 0; i + 2 <= e->ev_used[which]; i += 2) {
+        if (which == 0 && have_clean && !(i / 2 < e->ev_clean.size() && e->ev_clean[i / 2])) continue;
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, e->ev[which][i], e->ev[which][i + 1]));
         tot += ms;
