@@ -25,7 +25,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
     # name: (A, K per GPU, T, description)
@@ -47,11 +46,35 @@ def algorithmic_bytes_rollout(K, T, A):
     return K * (4 * T * A + 4)
 
 
-def cpu_baseline(A, K, T, budget_s=12.0):
-    """Serial oracle, full solve incl. its own sampler, same K/T; returns rollouts/s."""
+# goal / weights of the reference's YAML files (config/point_mass2d.yaml:6-16,
+# config/point_mass3d.yaml:6-20); 1-D and 4-D follow the same pattern
+PRESETS = {
+    1: ([1, 0], [1, 5]),
+    2: ([1, 0, 0, 0], [1, 1, 50, 50]),
+    3: ([1, .5, .75, 0, 0, 0], [1, 1, 1, 5, 5, 5]),
+    4: ([1, .5, .75, .25, 0, 0, 0, 0], [1, 1, 1, 1, 5, 5, 5, 5]),
+}
+
+
+def make_inputs(A, T):
+    """Synthetic inputs of the benchmark: x0 ~ 0.1 N(0,1) (seed 0), U0 = 0, the YAML goal / w,
+    dt = 0.1.  (The same values tests/oracle_lib.make_case(A, 1, T, seed=0, u_scale=0) produces;
+    written out here so that the GPU leg imports nothing of the oracle.)"""
     import numpy as np
+    rng = np.random.default_rng(0)
+    x0 = (rng.standard_normal(2 * A) * 0.1).astype(np.float32)
+    return {"x0": x0, "U": np.zeros((T, A), np.float32),
+            "goal": np.array(PRESETS[A][0], np.float32), "w": np.array(PRESETS[A][1], np.float32),
+            "dt": np.float32(0.1)}
+
+
+def cpu_baseline(A, K, T, budget_s=12.0):
+    """Serial oracle, full solve incl. its own sampler, same K/T; returns rollouts/s.  The ONLY
+    place where bench.py touches the oracle."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)
+    c = make_inputs(A, T)
     sig = [0.025] * A
     U = c["U"].copy()
     n = 0
@@ -105,7 +128,6 @@ def main():
 
     import numpy as np
     import torch
-    import oracle_lib as ol
     from mppi_gpu_amd import PointMassModel
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +153,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     A, K, T, desc = WORKLOADS[args.workload]
-    c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)      # x0 ~ 0.1 N(0,1), U0 = 0, yaml goal/w
+    c = make_inputs(A, T)                               # x0 ~ 0.1 N(0,1), U0 = 0, yaml goal/w
 
     if N == 1 and not args.force_sharded:
         m = PointMassModel(K, T, float(c["dt"]), 2 * A, A)
