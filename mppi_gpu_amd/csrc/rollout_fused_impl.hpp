@@ -128,6 +128,15 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         const unsigned long long kglob = (unsigned long long)(k_offset + kloc);
         const size_t tile = (size_t)(gid >> 6);
         float* etile = Eint + ((tile * nq) * 64 + lane) * 4;      // + q*256 floats per block
+        // the tile's slice of E as a raw buffer (base is wave-uniform: one tile = one wavefront)
+        __amdgpu_buffer_rsrc_t e_rsrc;
+        {
+            const unsigned long long tb = reinterpret_cast<unsigned long long>(Eint + (tile * nq) * 256);
+            const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)tb);
+            const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(tb >> 32));
+            e_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nq * 1024, 0x00020000);
+        }
 
         // ---- pass 1a: draw (or load) the chunk's noise into registers and store it ----------
         // `gi < ng` is wave-uniform.  Left to itself hipcc hoists the NG comparisons out of the tile
@@ -152,9 +161,23 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         box_muller_hw(r.z, r.w, z[2], z[3]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
-                        if (c * nq + q < NBT)      // blocks past the horizon are not stored
-                            *reinterpret_cast<float4*>(etile + (size_t)q * 256) =
-                                make_float4(eq[0], eq[1], eq[2], eq[3]);
+                        if (c * nq + q < NBT) {    // blocks past the horizon are not stored
+                            // Write-through store (sc0 sc1): E is not read again by this
+                            // launch, and what a plain store leaves dirty in the XCD L2s -- all
+                            // 16 MB at C2 -- is written back at the END of the kernel, where
+                            // nothing overlaps it (measured: 1.5 us of a 15 us launch).
+                            // (a raw buffer store with the sc0 sc1 cache policy: a compiler-
+                            //  known instruction, so hazards and wait counts stay hipcc's
+                            //  business -- an inline-asm global_store bypasses both and corrupted
+                            //  one word of some blocks; a volatile store is followed by a full
+                            //  wait (+34 % at 3-D K = 1e5); 8-byte system-scope atomic stores
+                            //  write half sectors (2x slower at K = 1e6))
+                            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                            const v4u val = {__float_as_uint(eq[0]), __float_as_uint(eq[1]),
+                                             __float_as_uint(eq[2]), __float_as_uint(eq[3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                                   17 /* sc0 | sc1 */);
+                        }
                     } else {
                         const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
                         eq[0] = t.x; eq[1] = t.y; eq[2] = t.z; eq[3] = t.w;
