@@ -8,7 +8,7 @@
 //                   64 lanes = 64/C trajectories x C time-chunks, lane = (k%(64/C))*C + c;
 //                   one float4 = the 4 normals of one Philox block (flat index n = t*A + a,
 //                   block n/4).  Every store and load of it is one full-wave contiguous
-//                   1 KiB global_store/load_dwordx4.
+//                   1 KiB dwordx4 access (stores: write-through buffer_store ... sc0 sc1).
 //   cost          : [K] floats.
 //   part_m/part_s : [grid] per-block running min and exp-sum (relative to that min).
 //   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
