@@ -5,10 +5,15 @@
 // 2-D, generalised to A axes.  BASELINE config 5: point_mass3d, K=1e5, T=200, 100 Hz re-plan ->
 // the solve must fit 10 ms.
 //
-//   mppi_closed_loop [-c config.yaml] [--dims A] [--samples K] [--horizon T] [--dt 0.1] [--model file.xml]
-//                    [--seconds S] [-t|--traj out.csv] [-s|--step-save prefix] [--lambda L] [--noise SIGMA]
+//   mppi_closed_loop [-c config.yaml] [-k key] [--dims A] [--samples K] [--horizon T] [--dt 0.1]
+//                    [--model file.xml] [--seconds S] [-t|--traj-save out.csv] [-s|--step-save prefix]
+//                    [--lambda L] [--noise SIGMA] [--max-a config|LIMIT]
 // -c reads a configuration file with the reference's keys (include/mppi_config.hpp); options
-// given after it override single values (the reference's -c/--config, src/main.cu:401-453))
+// given after it override single values (the reference's -c/--config, src/main.cu:401-453).
+// -k/--key (the reference's MuJoCo licence file, src/main.cu:417-423) is accepted and ignored: the
+// stand-in plant needs no key.  --max-a switches the action limit ON (the reference parses max-a,
+// src/main.cu:524,566-568, and never applies it, so the default is off): `config` takes the
+// file's max-a list, a number limits every axis to +-LIMIT.
 #include "mppi_config.hpp"
 #include "mppi_env.hpp"
 #include "point_mass.hpp"
@@ -86,7 +91,8 @@ int main(int argc, char** argv)
     float dt = 0.1f, lambda = 1.0f, sigma = 0.025f;
     double seconds = 2.0;
     std::string model, traj, step_prefix;
-    std::vector<float> cfg_goal, cfg_w, cfg_init;
+    std::vector<float> cfg_goal, cfg_w, cfg_init, cfg_max_a;
+    std::string max_a_opt;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
         if (k == "-c" || k == "--config") {
@@ -98,20 +104,24 @@ int main(int argc, char** argv)
             A = cfg.act_dim; K = cfg.samples; T = cfg.horizon; dt = cfg.dt; lambda = cfg.lambda;
             // the shipped files carry noise 0.25 while the reference's effective sigma is its
             // hard-coded 0.025; --noise overrides explicitly
-            cfg_goal = cfg.goal; cfg_w = cfg.cost_w; cfg_init = cfg.init_act;
+            cfg_goal = cfg.goal; cfg_w = cfg.cost_w; cfg_init = cfg.init_act; cfg_max_a = cfg.max_a;
             if (model.empty()) model = cfg.env;
-        } else if (k == "--dims") A = atoi(v.c_str());
+        } else if (k == "-k" || k == "--key") { /* licence key of the reference's MuJoCo: unused */ }
+        else if (k == "--max-a") max_a_opt = v;
+        else if (k == "--dims") A = atoi(v.c_str());
         else if (k == "--samples") K = atoi(v.c_str());
         else if (k == "--horizon") T = atoi(v.c_str());
         else if (k == "--dt") dt = (float)atof(v.c_str());
         else if (k == "--model") model = v;
         else if (k == "--seconds") seconds = atof(v.c_str());
-        else if (k == "--traj" || k == "-t") traj = v;
+        else if (k == "--traj" || k == "--traj-save" || k == "-t") traj = v;
         else if (k == "--step-save" || k == "-s") step_prefix = v;
         else if (k == "--lambda") lambda = (float)atof(v.c_str());
         else if (k == "--noise") sigma = (float)atof(v.c_str());
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
+    if (A < 1 || A > 4) { fprintf(stderr, "--dims must be 1..4, got %d\n", A); return 2; }
+    if (K < 1 || T < 1) { fprintf(stderr, "--samples and --horizon must be >= 1\n"); return 2; }
     const int S = 2 * A;
     // goal / cost.w of the shipped configs (reference config/point_mass{1,2,3}d.yaml)
     const float goals[4][8] = {{1, 0}, {1, 0, 0, 0}, {1, .5f, .75f, 0, 0, 0}, {1, .5f, .75f, .25f}};
@@ -128,6 +138,17 @@ int main(int argc, char** argv)
     PointMassModel* model_ctl = new PointMassModel(K, T, dt, S, A, false);
     std::vector<float> sig(A, sigma);
     model_ctl->set_params(lambda, sig.data(), nullptr);
+    if (!max_a_opt.empty()) {
+        std::vector<float> lim(A, (float)atof(max_a_opt.c_str()));
+        if (max_a_opt == "config") {
+            if ((int)cfg_max_a.size() != A) { fprintf(stderr, "--max-a config needs -c with max-a\n"); return 2; }
+            lim = cfg_max_a;
+        }
+        model_ctl->set_action_limit(lim.data());
+        printf("action limit on:");
+        for (float v : lim) printf(" %g", v);
+        printf("\n");
+    }
     std::vector<float> x(S), U(T * A, 0.0f), next_act(A), u_prev(T * A);
     if (!cfg_init.empty())          // reference init_action_seq, src/main.cu:678-684
         for (int t = 0; t < T; ++t)

@@ -13,9 +13,21 @@ barrier + torch.cuda.synchronize() on both sides; value = N*K*steps / max-over-r
 
 The JSON line also carries
   roofline      the rollout kernel (dominant): algorithmic HBM bytes per launch / its mean
-                duration from HIP events recorded on the launch stream inside the timed region
-  cpu_baseline  the serial CPU oracle (oracle/mppi_oracle.c + its own rocRAND-host sampler)
-                timed on this host on a bounded sample of the same workload, 1 thread
+                duration from HIP events recorded on the launch stream inside the timed region;
+                `traffic` (PMC HBM bytes) and `alu` (VALU issue-slot utilisation from the PMC
+                instruction counters) come from the committed rocprofv3 summaries of the same
+                command, and say so in `traffic_source` / `alu.source`
+  latency       the reference's timed unit (src/main.cu:329-332): blocking get_act + set_x,
+                measured after the timed region in the same process
+  cpu_baseline  the product's own serial CPU controller (ControllerBase through mppi_cpu_*, the
+                repo's "serial CPU path") on this host, 1 thread, on a bounded sample of the same
+                workload; `all_cores` the same with os.cpu_count() threads; `oracle` the CPU oracle
+                (oracle/mppi_oracle.c + rocRAND-host sampler) as a cross-check
+  extra.c4      with --gpus N > 1: config 4's strong-scaling leg (K = 1e6 global, K/N per rank)
+                timed after the headline region
+
+With --gpus N > 1 and no WORLD_SIZE in the environment, bench.py starts its N rank processes
+itself (one per GPU) before anything touches a GPU.
 """
 import argparse
 import json
@@ -36,6 +48,8 @@ WORKLOADS = {
     "c4full": (3, 1_000_000, 200, "point_mass3d K=1e6 T=200 on ONE GPU (BASELINE configs[3] unsharded)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+PROFILE_TRAFFIC = "traffic_r02.json"   # committed rocprofv3 --pmc summaries (profiles/README.md)
+PROFILE_ALU = "alu_r02.json"
 
 
 def algorithmic_bytes_rollout(K, T, A):
@@ -68,9 +82,9 @@ def make_inputs(A, T):
             "dt": np.float32(0.1)}
 
 
-def cpu_baseline(A, K, T, budget_s=12.0):
+def cpu_baseline_oracle(A, K, T, budget_s=6.0):
     """Serial oracle, full solve incl. its own sampler, same K/T; returns rollouts/s.  The ONLY
-    place where bench.py touches the oracle."""
+    place where bench.py touches the oracle (a cross-check of the product's CPU controller)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
@@ -88,6 +102,56 @@ def cpu_baseline(A, K, T, budget_s=12.0):
         n += 1
     assert np.isfinite(U).all()
     return K * n / t_tot, n
+
+
+def cpu_baseline_controller(A, K, T, threads, budget_s):
+    """The product's serial CPU path: ControllerBase (mppi_gpu_amd/csrc/controller_base.cpp: the
+    reference's class of that name made real) through the C ABI mppi_cpu_*,
+    full solves incl. its Philox + Box-Muller sampler on `threads` host threads."""
+    import numpy as np
+    from mppi_gpu_amd import ControllerBase
+    c = make_inputs(A, T)
+    ctl = ControllerBase(K, T, float(c["dt"]), 2 * A, A)
+    ctl.setActions(c["U"])
+    ctl.setCost(c["goal"], c["w"])
+    ctl.setSeed(0)
+    ctl.setThreads(threads)
+    n = 0
+    t_tot = 0.0
+    act = None
+    while t_tot < budget_s and n < 400:
+        t0 = time.perf_counter()
+        act = ctl.next(c["x0"])
+        t_tot += time.perf_counter() - t0
+        n += 1
+    assert np.isfinite(act).all()
+    ctl.close()
+    return K * n / t_tot, n
+
+
+def committed_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
+def spawn_ranks(n_gpus):
+    """--gpus N without a launcher: start the N rank processes (one per GPU) before anything here
+    touches a GPU, pass their output through and exit with the worst of their codes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
 
 
 def main():
@@ -130,12 +194,14 @@ def main():
     import torch
     from mppi_gpu_amd import PointMassModel
 
+    N = args.gpus
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(N)                  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    N = args.gpus
     if world != N:
-        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU fallback"
     if args.rehearse_one_gpu:
         local_rank = 0
@@ -219,30 +285,49 @@ def main():
     n_tiles = -(-K * geo["chunks"] // geo["block"])
     riding = (args.pipeline == 0 and not args.strict and not args.blocking
               and n_tiles <= 2 * geo["grid"])
+    kind = "ride" if riding else "plain"
+    prof_key = f"{args.workload}:chunks={geo['chunks']}:{kind}"
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
         ab = algorithmic_bytes_rollout(K, T, A)
         ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # PMC traffic cannot be collected from inside the timed process: it comes from the
-        # committed rocprofv3 --pmc summary of this workload/geometry (tools/traffic.sh), if any
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-            kind = "ride" if riding else "plain"
-            ent = tj["entries"].get(f"{args.workload}:chunks={geo['chunks']}:{kind}")
-            if ent and not geo["strict"]:
+        # PMC counters cannot be collected from inside the timed process: traffic, the rocprofv3
+        # kernel duration and the VALU figures come from the COMMITTED summaries of this
+        # workload/geometry (tools/traffic.sh, tools/kt.sh, tools/alu.sh), and are labelled so
+        traffic = traffic_src = None
+        tj = committed_profile(PROFILE_TRAFFIC)
+        if tj and not geo["strict"]:
+            ent = tj["entries"].get(prof_key)
+            if ent:
                 traffic = ent["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+                traffic_src = (f"committed profile profiles/{PROFILE_TRAFFIC} (rocprofv3 --pmc "
+                               "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command); not "
+                               "measured in this run")
         kname = ("k_rollout_stream" if geo["strict"] else
                  "k_rollout_ride (rollout of solve j + combine of solve j-1 in one launch)" if riding
                  else "k_rollout_fused")
         roof = {"bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
+                "kernel_ms_source": "HIP events stamped on the dispatch (hipExtLaunchKernelGGL), "
+                                    "second launch of each stamped pair, inside the timed region",
                 "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
+        aj = committed_profile(PROFILE_ALU)
+        if aj and not geo["strict"]:
+            ent = aj["entries"].get(prof_key)
+            if ent:
+                # rocprofv3's own average duration of the same kernel (profiled runs clock ~3-6 %
+                # lower than this un-profiled one) and the fraction it gives
+                if ent.get("kernel_ms_rocprof"):
+                    roof["kernel_ms_rocprof"] = ent["kernel_ms_rocprof"]
+                    roof["frac_rocprof"] = round(ab / (ent["kernel_ms_rocprof"] * 1e-3) / 1e9
+                                                 / HBM_PEAK_GBS, 4)
+                roof["alu"] = dict(ent["alu"], source=f"committed profile profiles/{PROFILE_ALU} "
+                                   "(rocprofv3 --pmc SQ instruction counters, same command); not "
+                                   "measured in this run")
         if riding and sharded is None:
             # for reference, outside the timed region: the two kernels on their own (eager mode,
             # one rollout launch + one combine launch per solve)
@@ -258,6 +343,64 @@ def main():
             roof["solo"] = {"rollout_kernel_ms": round(r_ms, 5), "combine_kernel_ms": round(c2_ms, 5),
                             "rollout_frac": round(ab / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                             if r_ms > 0 else None}
+    m.set_profiling(0)
+
+    # ---- the reference's timed unit: a blocking get_act (+ set_x: the closed loop) -----------
+    latency = None
+    if not args.blocking and not args.inject:
+        eng = sharded or m
+        n_lat = 300 if K <= 200_000 else 50
+        x_now = c["x0"].copy()
+        for _ in range(20):
+            eng.get_act()
+        fence()
+        tl = time.perf_counter()
+        for _ in range(n_lat):
+            eng.get_act()
+        t_get = (time.perf_counter() - tl) / n_lat
+        tl = time.perf_counter()
+        for _ in range(n_lat):
+            eng.get_act()
+            m.set_x(x_now)
+        t_loop = (time.perf_counter() - tl) / n_lat
+        if dist is not None:
+            tt = torch.tensor([t_get, t_loop], device="cpu" if args.rehearse_one_gpu else "cuda",
+                              dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_get, t_loop = (float(v) for v in tt.tolist())
+        latency = {"blocking_get_act_ms": round(t_get * 1e3, 5),
+                   "blocking_get_act_plus_set_x_ms": round(t_loop * 1e3, 5),
+                   "rollouts_per_s_blocking": N * K / t_get, "calls": n_lat,
+                   "what": "PointMassModel.get_act() through the Python binding: launch, solve, "
+                           "wait for the action in host memory (reference src/main.cu:329-332)"}
+
+    # ---- config 4's strong-scaling leg (K = 1e6 global) when run on several GPUs ---------------
+    extra = {}
+    if N > 1 and not args.rehearse_one_gpu and args.workload != "c4":
+        from mppi_gpu_amd.sharded import ShardedPointMassModel
+        A4, T4, K4 = 3, 200, 1_000_000
+        c4 = make_inputs(A4, T4)
+        s4 = ShardedPointMassModel(K4, T4, float(c4["dt"]), 2 * A4, A4, transport=args.transport)
+        s4.engine.set_seed(0)
+        s4.memcpy_set_data(c4["x0"], c4["U"], c4["goal"], c4["w"])
+        for _ in range(20):
+            s4.solve_async()
+        dist.barrier(); torch.cuda.synchronize(); s4.engine.sync_act()
+        n4 = 200
+        t4 = time.perf_counter()
+        for _ in range(n4):
+            s4.solve_async()
+        dist.barrier(); torch.cuda.synchronize(); s4.engine.sync_act()
+        d4 = time.perf_counter() - t4
+        tt = torch.tensor([d4], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        d4 = float(tt.item())
+        extra["c4"] = {"workload": "point_mass3d K=1e6 T=200 sharded over the ranks (BASELINE "
+                                   "configs[3]), strong scaling", "global_rollouts": K4,
+                       "rollouts_per_gpu": s4.engine.K, "steps": n4, "ms_per_step": d4 / n4 * 1e3,
+                       "value": K4 * n4 / d4, "unit": "rollouts/s", "scaling": "strong",
+                       "exchange": s4.transport, "exchange_validated": getattr(s4, "validated", None)}
+        s4.close()
 
     if rank == 0:
         value = N * K * args.steps / dt_s
@@ -271,18 +414,33 @@ def main():
                      "synthetic"),
             "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
                        "global_rollouts": N * K, "sharding": f"samples x{N}",
+                       "mode": "blocking get_act per step" if args.blocking else
+                               "solves enqueued back to back (mppi_solve_async), one wait at the end",
                        "exchange": None if sharded is None else
-                       {"direct": "combine kernel -> peer inboxes over xGMI (hipIpc), no collective",
-                        "collective": "RCCL all-gather of T*A+2 floats"}[sharded.transport],
+                       {"transport": sharded.transport,
+                        "what": {"direct": "combine kernel -> peer inboxes over xGMI (hipIpc), no collective",
+                                 "collective": "RCCL all-gather of T*A+2 floats"}[sharded.transport],
+                        "validated_against_collective": getattr(sharded, "validated", None)},
                        "geometry": geo, "rollout_steps_per_s": value * T},
             "roofline": roof,
+            "latency": latency,
         }
+        if extra:
+            line["extra"] = extra
         if N == 1 and not args.no_cpu_baseline:
-            v, nsolves = cpu_baseline(A, K, T)
+            ncores = os.cpu_count() or 1
+            v1, n1 = cpu_baseline_controller(A, K, T, 1, 10.0)
             line["cpu_baseline"] = {
-                "value": v, "unit": "rollouts/s", "cores": 1, "kind": "port",
-                "sample": f"{nsolves} full serial solves of the same workload (K={K}, T={T}, A={A}), "
-                          "oracle/mppi_oracle.c + rocRAND-host Philox sampler, 1 thread"}
+                "value": v1, "unit": "rollouts/s", "cores": 1, "kind": "port",
+                "sample": f"{n1} full solves of the same workload (K={K}, T={T}, A={A}) by the "
+                          "product's serial CPU controller (ControllerBase via mppi_cpu_*: Philox + "
+                          "Box-Muller sampler, rollout, cost, beta, nabla, update, shift), 1 thread"}
+            va, na = cpu_baseline_controller(A, K, T, ncores, 5.0)
+            line["cpu_baseline"]["all_cores"] = {"value": va, "cores": ncores, "solves": na}
+            vo, no = cpu_baseline_oracle(A, K, T)
+            line["cpu_baseline"]["oracle"] = {
+                "value": vo, "cores": 1, "solves": no,
+                "what": "oracle/mppi_oracle.c + rocRAND-host Philox sampler (the checker), cross-check"}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

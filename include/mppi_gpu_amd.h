@@ -95,10 +95,19 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed);
  * the reference exposes E as an I/O buffer, src/point_mass.cu:232,251). NULL = sample again. */
 int mppi_set_noise(mppi_engine* e, const float* noise);
 
-/* Reproduce the reference's update_act sample-coverage defect for act_dim == 3
- * (src/point_mass.cu:387,402,839-842). Default off = mathematically
- * correct update. */
+/* Reproduce the reference's update_act sample-coverage defects: act_dim 3 sums
+ * only the first 512*(K/768+1) samples (src/point_mass.cu:387,402,839-842); act_dim 1 sums only
+ * the samples k with k even and (k/512) even, because the block trees stop one fold early
+ * (src/point_mass.cu:893,709; supported for nb_sim < 262144).  act_dim 2 is exact in the reference.
+ * Default off = mathematically correct update. */
 int mppi_set_ref_compat(mppi_engine* e, int on);
+
+/* Opt-in action limit: the updated controls (every step of the sequence, hence the returned
+ * action) are clamped to [-max_a[a], +max_a[a]] per axis inside the combine kernel; NULL switches
+ * it off (default).  The reference parses `max-a` from its YAML (src/main.cu:524,566-568) and
+ * never hands it to the controller: default off = the reference's effective
+ * behaviour. */
+int mppi_set_action_limit(mppi_engine* e, const float* max_a);
 
 /* Kernel shape. chunks = lanes cooperating on one trajectory (power of two, 1..64; 0 = auto);
  * strict != 0 selects the sequential, association-faithful rollout kernel (one lane per
@@ -162,8 +171,13 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
  * mppi_solve_local_async + all-gather + mppi_solve_finish_async.  In pipeline mode 0 that launch
  * is deferred like the single-GPU combine: with solves enqueued back to back it rides in the next
  * solve's rollout launch, and the peers' words arrive while this rank draws the next noise.
- * All ranks must make the same sequence of exchange calls; a rank that waits longer than the time-out (default 5 s) gives up,
- * and the next mppi_sync_act / mppi_get_act returns MPPI_ESTATE.  world <= 64. */
+ * All ranks must make the same sequence of exchange calls; a rank that waits longer than the
+ * time-out (default 5 s) gives up WITHOUT applying or publishing anything for the columns it
+ * missed, and the fault is sticky: every later solve or read-out call on the engine returns
+ * MPPI_ESTATE until mppi_set_data starts over (fresh controls, solve counter 0).  The same holds
+ * for the single-GPU watchdog (a block that waits 2 s for the combine riding in its own launch).
+ * mppi_xchg_close completes a solve whose exchange is still held back before it frees the inbox
+ * and reports a time-out of that exchange.  world <= 64. */
 int mppi_xchg_handle_bytes(void);
 int mppi_xchg_open(mppi_engine* e, int rank, int world, void* handle_out, void** inbox_out);
 int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_process);

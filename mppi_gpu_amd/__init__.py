@@ -159,6 +159,15 @@ class PointMassModel:
     def set_ref_compat(self, on):
         check(self._lib.mppi_set_ref_compat(self._h, int(bool(on))))
 
+    def set_action_limit(self, max_a):
+        """Opt-in clamp of the updated controls to +-max_a[axis] (None = off, the reference's
+        effective behaviour: it parses max-a and drops it, src/main.cu:566-568)."""
+        if max_a is None:
+            check(self._lib.mppi_set_action_limit(self._h, C.cast(None, _capi.c_float_p)))
+            return
+        m = _f32(max_a, self.A, "max_a")
+        check(self._lib.mppi_set_action_limit(self._h, _fp(m)))
+
     def set_tuning(self, chunks=0, strict=False, max_blocks=0):
         check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
 

@@ -49,12 +49,19 @@ __device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigne
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Has a block of some launch of this engine already given up waiting?  (the device watchdog
+// word; sticky until mppi_set_data)  Later launches then neither wait nor publish anything.
+__device__ __forceinline__ bool watchdog_tripped(const int* err_dev)
+{
+    return err_dev && __hip_atomic_load(err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 // Poll inbox word p1 (and p2 when non-null, both loads in flight together) until they carry
 // `tag`; bounded by the exchange time-out so that every wave reaches its exit whatever the
-// peers do.
+// peers do, and cut short once the watchdog word says that somebody else has given up.
 __device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const unsigned long long* p2,
                                          unsigned int tag, unsigned long long limit, float& v1,
-                                         float& v2, int& timed_out)
+                                         float& v2, int& timed_out, const int* err_dev = nullptr)
 {
     const unsigned long long t0 = wall_clock64();
     bool ok1 = (p1 == nullptr), ok2 = (p2 == nullptr);
@@ -73,7 +80,7 @@ __device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const uns
             ok2 = true;
         }
         if (ok1 && ok2) return;
-        if (wall_clock64() - t0 > limit) {
+        if (wall_clock64() - t0 > limit || watchdog_tripped(err_dev)) {
             timed_out = 1;
             return;
         }
@@ -81,11 +88,18 @@ __device__ __forceinline__ void ll_poll2(const unsigned long long* p1, const uns
     }
 }
 
-// The update of one control value: the same expression wherever it is evaluated (combine blocks,
-// rollout blocks that rebuild the controls from the tagged split sums), hence the same bits.
-__device__ __forceinline__ float updated_control(float uin, float tot, float nabla)
+// The update of one control value (column n = t*A + axis): the same expression wherever it is
+// evaluated, hence the same bits.  With a.clamp the result is limited to the axis' +-max_a
+// (opt-in; the reference parses max-a and never applies it, src/main.cu:524,566-568).
+__device__ __forceinline__ float updated_control(const CombineArgs& a, int n, float uin, float tot,
+                                                 float nabla)
 {
-    return uin + tot / nabla;
+    float unew = uin + tot / nabla;
+    if (a.clamp) {
+        const float lim = a.max_a[n % a.A];
+        unew = fminf(fmaxf(unew, -lim), lim);
+    }
+    return unew;
 }
 
 // Write column n of the updated, shifted controls (and the action).
@@ -121,7 +135,7 @@ __device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int
         tot = fmaf(r, xv[g * kCombineCols + tid], tot);
     }
     if (n < a.TA) {
-        const float unew = updated_control(uin, tot, nabla);
+        const float unew = updated_control(a, n, uin, tot, nabla);
         publish_control(a, n, unew);
         if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
     }
@@ -135,7 +149,7 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float
                                               float nabla)
 {
     if (a.final_mode) {
-        const float unew = updated_control(uin, tot, nabla);
+        const float unew = updated_control(a, n, uin, tot, nabla);
         publish_control(a, n, unew);
         if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
     } else {
@@ -257,6 +271,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     // that applies them); apply_blk is block-uniform
     float mine = tot;
     bool apply_blk = true;
+    int timed_out = 0;         // this thread gave up on a word: it publishes nothing
     if (a.slab_tag) {
         // Fence-free meeting of the row splits (the 256-thread shape, which may run inside a busy
         // rollout launch): splits 0 .. RS-2 publish their sums as tagged 8-byte words and are done;
@@ -270,12 +285,11 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
         }
         if (RS > 1 && tid < kCombineCols && n < a.TA) {
             float t2 = 0.0f;
-            int timed_out = 0;
             for (int q0 = 0; q0 < RS - 1; q0 += 2) {
                 const unsigned long long* p1 = a.slab_tag + (size_t)q0 * a.TA + n;
                 const unsigned long long* p2 = (q0 + 1 < RS - 1) ? p1 + a.TA : nullptr;
                 float v1, v2;
-                ll_poll2(p1, p2, tag, a.x.timeout_ticks, v1, v2, timed_out);
+                ll_poll2(p1, p2, tag, a.x.timeout_ticks, v1, v2, timed_out, a.x.err_dev);
                 t2 += v1;
                 if (p2) t2 += v2;
             }
@@ -316,7 +330,10 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
         }
     }
     if (a.final_mode != 2) {
-        if (apply_blk && tid < kCombineCols && n < a.TA) combine_apply(a, n, uin, mine, nabla);
+        // (a column whose sums did not arrive in time is left alone: the watchdog word is set, the
+        //  host reports MPPI_ESTATE from then on and hands out nothing until mppi_set_data)
+        if (apply_blk && !timed_out && tid < kCombineCols && n < a.TA)
+            combine_apply(a, n, uin, mine, nabla);
         if (cb == 0 && rs == RS - 1 && tid == 0) {
             if (a.final_mode) {
                 a.dev->beta = beta;
@@ -337,8 +354,15 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     float* xs = xm + kMaxRanks;                          // [G]
     float* mine_lds = xs + kMaxRanks;                    // [16]
     __syncthreads();
+    if (tid == 0) last_flag = 0;
+    __syncthreads();
+    // a block that missed a word -- a row split's sum above, a peer's word below -- sends and
+    // publishes nothing: its peers time out as well, the controls stay as they were, and every
+    // host reports MPPI_ESTATE until mppi_set_data
+    if (timed_out) last_flag = 1;
     if (tid < kCombineCols) mine_lds[tid] = (n < a.TA) ? mine : 0.0f;
     __syncthreads();
+    if (last_flag) return;
     const int c = tid & (kCombineCols - 1);
     const int nn = cb * kCombineCols + c;
     const size_t slot_w = (size_t)x.W;
@@ -351,12 +375,11 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
             ll_store(dst + 1, nabla, x.tag);
         }
     }
-    int timed_out = 0;
     for (int g = tid / kCombineCols; g < x.G; g += GPB) {
         const unsigned long long* src = x.peers[x.rank] + ((size_t)x.parity * x.G + g) * slot_w;
         float v1, v2;   // column word of rank g; columns 0 / 1 also fetch beta_g / S_g
         ll_poll2((nn < a.TA) ? src + 2 + nn : nullptr, (c < 2) ? src + c : nullptr, x.tag,
-                 x.timeout_ticks, v1, v2, timed_out);
+                 x.timeout_ticks, v1, v2, timed_out, x.err_dev);
         xv[g * kCombineCols + c] = v1;
         if (c == 0) xm[g] = v2;
         if (c == 1) xs[g] = v2;
@@ -364,8 +387,10 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     if (timed_out) {
         *x.err_dev = 1;
         if (x.err_host) *x.err_host = 1;
+        last_flag = 1;
     }
     __syncthreads();
+    if (last_flag) return;
     finish_columns(a, cb, tid, x.G, xm, xs, xv, uin);
 }
 

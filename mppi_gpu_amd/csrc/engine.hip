@@ -86,7 +86,13 @@ struct mppi_engine {
     unsigned long long solve_idx = 0;       // solves since set_data
     bool data_set = false, have_solve = false;
     bool ref_compat = false;
+    bool clamp = false;                     // opt-in action limit (mppi_set_action_limit)
+    float max_a[4] = {0.f, 0.f, 0.f, 0.f};
     int verbose = 0;
+    int fault = 0;                          // sticky device-watchdog code, cleared by mppi_set_data
+    // tuning aids, read from the environment ONCE at mppi_create (never per launch)
+    int tune_combine_splits = 0;            // MPPI_COMBINE_SPLITS: row splits of the combine, 0 = auto
+    int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
 
     // geometry
     int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
@@ -275,15 +281,29 @@ int ensure_geometry(mppi_engine_t* e)
     e->n_tileblk = (int)ntb;
     e->grid = grid;
     e->geom_ok = true;
+    e->args_valid = false;
     e->inj_dirty = e->injected;
     return MPPI_OK;
 }
 
+// ref_compat: which samples the reference's update_act sums.
+//   act_dim 3: the grid K/(256*3)+1 covers only the first 512*(K/768+1) samples, each block
+//              taking 512 (reference src/point_mass.cu:387,402,839-842);
+//   act_dim 1: the in-block tree stops at s > 1 (:893, and :709 in sum_red_adim), so of every
+//              256-thread block only the even threads' sums reach the block partial, and at the
+//              second level only the even blocks' partials reach the result: samples k with k even
+//              and, once there is a second level (K >= 256), (k / 512) even.
 long long ref_cover(const mppi_engine_t* e)
 {
     if (!e->ref_compat || e->A != 3) return 0x7fffffffffffffffLL;
-    long long cov = 512LL * (e->K / 768 + 1);   // reference src/point_mass.cu:387,402,839-842
+    long long cov = 512LL * (e->K / 768 + 1);
     return cov < e->K ? cov : e->K;
+}
+
+unsigned int ref_cover_and(const mppi_engine_t* e)
+{
+    if (!e->ref_compat || e->A != 1) return 0u;
+    return e->K >= 256 ? 0x201u : 0x1u;
 }
 
 void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
@@ -302,6 +322,7 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.part_N = e->d_pN;
     a.k_offset = e->k_offset;
     a.k_cover = ref_cover(e);
+    a.cover_and = ref_cover_and(e);
     a.seed = e->seed;
     a.solve_idx = e->solve_idx;
     a.K = e->K;
@@ -390,8 +411,9 @@ void fill_own_combine(mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long lon
         ca.x.parity = (int)(xseq & 1ull);
         ca.x.tag = (unsigned int)(xseq % 0xFFFFFFFFull) + 1u;
     }
-    const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
-    ca.row_splits = env ? atoi(env) : 0;
+    ca.row_splits = e->tune_combine_splits;
+    ca.clamp = e->clamp ? 1 : 0;
+    for (int i = 0; i < 4; ++i) ca.max_a[i] = e->max_a[i];
 #ifdef MPPI_TRACE
     ca.trace = mppi::g_mppi_trace_buf;
 #endif
@@ -426,18 +448,30 @@ void read_action(const mppi_engine_t* e, float* next_act)
     }
 }
 
-// report (and clear) what a device-side time-out left in the watchdog word
+// Report what a device-side time-out left in the watchdog word.  The fault is STICKY: the block
+// that gave up published nothing, so the controls on the device are those of the last complete
+// solve at best; every call that would solve or hand out results fails with MPPI_ESTATE until
+// mppi_set_data starts over (it re-uploads the controls and clears the word).
 int check_watchdog(mppi_engine_t* e)
 {
-    if (!e->h_err || !*e->h_err) return MPPI_OK;
-    const int code = *e->h_err;
-    *e->h_err = 0;
-    (void)hipMemset(e->d_err, 0, sizeof(int));
+    if (!e->fault && e->h_err && *e->h_err) e->fault = *e->h_err;
+    if (!e->fault) return MPPI_OK;
+    const int code = e->fault;
     if (code == 1)
         return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
                     "solve %llu", e->xg_timeout_s, e->solve_idx);
     return fail(MPPI_ESTATE, "device watchdog %d: a block gave up waiting for the combine that "
-                "rides in its own launch", code);
+                "rides in its own launch (call mppi_set_data to start over)", code);
+}
+
+// forget a reported fault: everything enqueued has drained (the caller settled), so no kernel can
+// set the word again
+int clear_watchdog(mppi_engine_t* e)
+{
+    e->fault = 0;
+    if (e->h_err) *e->h_err = 0;
+    if (e->d_err) HIPCHK(hipMemset(e->d_err, 0, sizeof(int)));
+    return MPPI_OK;
 }
 
 // everything enqueued by this engine has run, nothing is pending
@@ -462,11 +496,8 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         // rollout blocks, against the ~8 us of a stand-alone combine launch.  With more than two
         // tiles per block the pending combine is launched on its own instead (same kernel code,
         // same bits).
-        static const int max_tiles = [] {
-            const char* env = getenv("MPPI_RIDE_MAX_TILES");   // tuning aid
-            return env ? atoi(env) : 2;
-        }();
-        const bool short_launch = (long long)e->n_tileblk <= (long long)max_tiles * e->grid;
+        const bool short_launch =
+            (long long)e->n_tileblk <= (long long)e->tune_ride_max_tiles * e->grid;
         if (!carry || e->strict || e->pending_stream != st || !short_launch) {
             const hipStream_t was = e->pending_stream;
             if ((rc = flush_pending(e))) return rc;
@@ -486,17 +517,17 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     fill_rollout_args(e, ra);
     ra.Eint = Ecur;
     ra.dev_copy = e->d_args;
-    {   // refresh the device copy only when something other than the per-solve fields changed
+    if (!e->args_valid) {
+        // The device copy holds what does not change from solve to solve; every setter that touches
+        // one of its fields clears args_valid (solve index, noise pointer and x0 travel by value).
         mppi::RolloutArgs cmp = ra;
         cmp.solve_idx = 0;
-        cmp.Eint = nullptr;                            // travels by value
-        for (int i = 0; i < 8; ++i) cmp.x0[i] = 0.f;   // travels by value
-        if (!e->args_valid || memcmp(&cmp, &e->h_args_last, sizeof cmp) != 0) {
-            HIPCHK(hipMemcpyAsync(e->d_args, &cmp, sizeof cmp, hipMemcpyHostToDevice, st));
-            HIPCHK(hipStreamSynchronize(st));
-            e->h_args_last = cmp;
-            e->args_valid = true;
-        }
+        cmp.Eint = nullptr;
+        for (int i = 0; i < 8; ++i) cmp.x0[i] = 0.f;
+        HIPCHK(hipMemcpyAsync(e->d_args, &cmp, sizeof cmp, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->h_args_last = cmp;
+        e->args_valid = true;
     }
     mppi::DeferredCombine dc;
     memset(&dc, 0, sizeof dc);
@@ -565,10 +596,9 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
         ca.x.err_dev = e->d_err;
         ca.x.err_host = e->h_err_dev;
     }
-    {
-        const char* env = getenv("MPPI_COMBINE_SPLITS");   // tuning aid
-        ca.row_splits = env ? atoi(env) : 0;
-    }
+    ca.row_splits = e->tune_combine_splits;
+    ca.clamp = e->clamp ? 1 : 0;
+    for (int i = 0; i < 4; ++i) ca.max_a[i] = e->max_a[i];
     mppi::LaunchTiming tm;
     {
         int rc = prof_pair(e, tm, 1);
@@ -590,8 +620,20 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(MPPI_ENODEV, "no HIP device: the engine has no CPU fallback");
+    {   // The library's code object must load on this device and hold the kernels this engine will
+        // launch: asked for here, a mismatch (wrong --offload-arch, a partly rebuilt library) is an
+        // error code; found at the first launch it is an abort() inside the HIP runtime.
+        const hipError_t pe = mppi::probe_code_object(A);
+        if (pe != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(MPPI_ENODEV, "the gfx950 kernels of this library cannot be loaded on the "
+                        "current device: HIP error %d (%s)", (int)pe, hipGetErrorString(pe));
+        }
+    }
 
     mppi_engine* e = new mppi_engine();
+    if (const char* env = getenv("MPPI_COMBINE_SPLITS")) e->tune_combine_splits = atoi(env);
+    if (const char* env = getenv("MPPI_RIDE_MAX_TILES")) e->tune_ride_max_tiles = atoi(env);
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
     e->SG = mppi::rollout_group_steps(A);
     e->BPG = mppi::rollout_group_blocks(A);
@@ -715,7 +757,12 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
         int rc_ = settle(e);
         if (rc_) return rc_;
     }
+    {   // everything has drained: a reported device time-out ends here (fresh controls below)
+        int rc_ = clear_watchdog(e);
+        if (rc_) return rc_;
+    }
     for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
+    e->args_valid = false;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
     e->have_solve = false;
     HIPCHK(hipMemcpy(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice));
@@ -747,7 +794,7 @@ int mppi_get_x(mppi_engine* e, float* x0)
 int mppi_solve_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    if (e->h_err && *e->h_err) return check_watchdog(e);   // fail fast after a device time-out
+    if (e->fault || (e->h_err && *e->h_err)) return check_watchdog(e);   // sticky until set_data
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
@@ -781,8 +828,12 @@ int mppi_sync_act(mppi_engine* e, float* next_act)
         int rc = settle(e);
         if (rc) return rc;
     }
+    {
+        int rc = check_watchdog(e);
+        if (rc) return rc;
+    }
     if (next_act) read_action(e, next_act);
-    return check_watchdog(e);
+    return MPPI_OK;
 }
 
 int mppi_get_act(mppi_engine* e, float* next_act)
@@ -809,8 +860,9 @@ int mppi_get_act(mppi_engine* e, float* next_act)
             break;
         }
     }
+    if ((rc = check_watchdog(e))) return rc;
     read_action(e, next_act);
-    return check_watchdog(e);
+    return MPPI_OK;
 }
 
 int mppi_get_u(mppi_engine* e, float* u)
@@ -819,6 +871,7 @@ int mppi_get_u(mppi_engine* e, float* u)
     {
         int rc_ = settle(e);
         if (rc_) return rc_;
+        if ((rc_ = check_watchdog(e))) return rc_;
     }
     HIPCHK(hipMemcpy(u, e->d_U + (e->solve_idx & 1ull) * e->TA, (size_t)e->TA * sizeof(float),
                      hipMemcpyDeviceToHost));
@@ -832,6 +885,7 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     {
         int rc_ = settle(e);
         if (rc_) return rc_;
+        if ((rc_ = check_watchdog(e))) return rc_;
     }
     if ((x_all || noise || cost || beta || nabla || weight) && !e->have_solve)
         return fail(MPPI_ESTATE, "no solve has run since mppi_set_data");
@@ -902,6 +956,7 @@ int mppi_set_params(mppi_engine* e, float lambda, const float* sigma, const floa
     if (sigma)
         for (int i = 0; i < e->A; ++i) e->sigma[i] = sigma[i];
     if (inv_s) for (int i = 0; i < e->A; ++i) e->inv_s[i] = inv_s[i];
+    e->args_valid = false;
     return MPPI_OK;
 }
 
@@ -909,6 +964,7 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     e->seed = seed;
+    e->args_valid = false;
     return MPPI_OK;
 }
 
@@ -934,14 +990,33 @@ int mppi_set_noise(mppi_engine* e, const float* noise)
 int mppi_set_ref_compat(mppi_engine* e, int on)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    if (on && e->A == 1)
-        return fail(MPPI_EINVAL, "ref_compat for act_dim 1 is not implemented");
+    if (on && e->A == 1 && e->K >= 262144)
+        return fail(MPPI_EINVAL, "ref_compat for act_dim 1 covers nb_sim < 262144 (beyond that the "
+                    "reference's in-place multi-block passes race, SURVEY App. B.1)");
+    if (on && e->A == 4)
+        return fail(MPPI_EINVAL, "ref_compat: the reference has no 4-D system to be compatible with");
     if (on && e->sharded) return fail(MPPI_EINVAL, "ref_compat is single-GPU only");
     {
         int rc_ = flush_pending(e);
         if (rc_) return rc_;
     }
     e->ref_compat = on != 0;
+    e->args_valid = false;
+    return MPPI_OK;
+}
+
+int mppi_set_action_limit(mppi_engine* e, const float* max_a)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (max_a)
+        for (int i = 0; i < e->A; ++i)
+            if (!(max_a[i] >= 0.f)) return fail(MPPI_EINVAL, "max_a[%d] must be >= 0", i);
+    {   // a pending combine belongs to the old setting
+        int rc_ = flush_pending(e);
+        if (rc_) return rc_;
+    }
+    e->clamp = max_a != nullptr;
+    for (int i = 0; i < e->A; ++i) e->max_a[i] = max_a ? max_a[i] : 0.f;
     return MPPI_OK;
 }
 
@@ -1015,6 +1090,8 @@ int mppi_solve_finish_async(mppi_engine* e, const float* d_gathered, int n_parts
     ca.act_tag = next_act_tag(e);
     ca.solve_idx = e->solve_idx;
     ca.final_mode = 1;
+    ca.clamp = e->clamp ? 1 : 0;
+    for (int i = 0; i < 4; ++i) ca.max_a[i] = e->max_a[i];
     HIPCHK(mppi::launch_finish_gathered(ca, d_gathered, n_parts, st));
     e->last_stream = st;
     e->solve_idx += 1;
@@ -1082,6 +1159,7 @@ int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_pro
     HIPCHK(hipMemcpy(e->d_xg_peers, tab.data(), mppi::kMaxRanks * sizeof(void*),
                      hipMemcpyHostToDevice));
     e->xg_connected = true;
+    e->args_valid = false;      // the riding rollout's watchdog outwaits the exchange time-out
     return MPPI_OK;
 }
 
@@ -1089,16 +1167,17 @@ int mppi_xchg_set_timeout(mppi_engine* e, double seconds)
 {
     if (!e || !(seconds > 0.0) || seconds > 60.0) return fail(MPPI_EINVAL, "timeout in (0, 60] s");
     e->xg_timeout_s = seconds;
+    e->args_valid = false;
     return MPPI_OK;
 }
 
 int mppi_xchg_close(mppi_engine* e)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
-    if (e->pending && e->pending_mode == 2)
-        e->pending = false;     // an exchange nobody waited for cannot complete without its inbox
-    else
-        (void)flush_pending(e);
+    // A solve whose exchange is still held back is completed while the inboxes exist (its solve and
+    // exchange counters have advanced already; the peers, having made the same calls, hold theirs);
+    // a peer that is gone shows up as the exchange time-out, reported below.
+    int rc = flush_pending(e);
     if (e->last_stream) (void)hipStreamSynchronize(e->last_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* p : e->xg_opened) (void)hipIpcCloseMemHandle(p);
@@ -1106,14 +1185,16 @@ int mppi_xchg_close(mppi_engine* e)
     if (e->xg_inbox) (void)hipFree(e->xg_inbox);
     e->xg_inbox = nullptr;
     e->xg_connected = false;
-    return MPPI_OK;
+    e->args_valid = false;
+    if (rc) return rc;
+    return check_watchdog(e);
 }
 
 int mppi_solve_exchange_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (!e->xg_connected) return fail(MPPI_ESTATE, "mppi_xchg_connect has not been called");
-    if (e->h_err && *e->h_err) return check_watchdog(e);   // fail fast after a device time-out
+    if (e->fault || (e->h_err && *e->h_err)) return check_watchdog(e);   // sticky until set_data
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);

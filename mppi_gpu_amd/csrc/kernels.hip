@@ -109,7 +109,8 @@ k_rollout_stream(const RolloutArgs* __restrict__ gp, float* __restrict__ Eint,
             const float sw = wave_sum(wt);
             if (lane == 0) misc[4 + wave] = sw;
         }
-        const float wtN = ((long long)kglob < g.k_cover) ? wt : 0.0f;
+        const float wtN =
+            ((long long)kglob < g.k_cover && ((unsigned int)kglob & g.cover_and) == 0u) ? wt : 0.0f;
         for (int q = 0; q < nq; ++q) {
             const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
             const float ev[4] = {t.x, t.y, t.z, t.w};
@@ -327,6 +328,24 @@ hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const Rol
         case 4: return launch_fused_a<4>(NGt, sample, grid, a, d, st, tm);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t probe_code_object(int A)
+{
+    hipFuncAttributes fa;
+    hipError_t rc = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_combine_small));
+    if (rc != hipSuccess) return rc;
+    switch (A) {
+        case 1: rc = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_rollout_stream<1, true>)); break;
+        case 2: rc = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_rollout_stream<2, true>)); break;
+        case 3: rc = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_rollout_stream<3, true>)); break;
+        case 4: rc = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_rollout_stream<4, true>)); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (rc != hipSuccess) return rc;
+    // the fused rollout lives in its own translation unit: the occupancy query resolves its symbol
+    return rollout_blocks_per_cu(A, 1, true, rollout_lds_bytes(8, 16)) > 0 ? hipSuccess
+                                                                             : hipErrorInvalidDeviceFunction;
 }
 
 int combine_small_prepare(CombineArgs& a)

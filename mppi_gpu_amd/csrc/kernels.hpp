@@ -38,7 +38,8 @@ struct RolloutArgs {
     float* part_s;         // [grid]
     float* part_N;         // [grid][TA]
     long long k_offset;    // global index of local sample 0 (Philox subsequence base)
-    long long k_cover;     // samples with GLOBAL index >= k_cover get zero update weight
+    long long k_cover;     // samples with GLOBAL index >= k_cover get zero update weight,
+    unsigned int cover_and; // and so do samples with (index & cover_and) != 0 (ref_compat masks)
     unsigned long long seed;
     unsigned long long solve_idx;   // solves since set_data: Philox offset, U buffer parity
     int K;                 // local samples
@@ -114,10 +115,12 @@ inline RolloutHot make_hot(const RolloutArgs& a)
 #ifdef MPPI_TRACE
     h.trace = g_mppi_trace_buf;
 #endif
-    if (const char* dbg = getenv("MPPI_DEBUG_SKIP")) {   // latency probes, never set in production
+#ifdef MPPI_TRACE      // latency probes of the analysis build only: the product never reads them
+    if (const char* dbg = getenv("MPPI_DEBUG_SKIP")) {
         h.n_tileblk = 0;                                 // 1: prologue + epilogue only
         if (dbg[0] == '2') { h.NBTp = 0; h.TA = 0; }     // 2: (almost) empty kernel
     }
+#endif
     return h;
 }
 
@@ -167,6 +170,8 @@ struct CombineArgs {
     int final_mode;        // 0 partial -> partial_out, 1 final, 2 partial -> peer exchange -> final
     XchgArgs x;            // final_mode 2 only
     int row_splits;        // 0 = auto
+    int clamp;             // != 0: updated controls are limited to [-max_a[axis], +max_a[axis]]
+    float max_a[4];        // (the reference parses max-a and drops it, src/main.cu:566-568: opt-in)
     int n_cols, RS;        // filled by the launcher: column blocks and row splits of the grid
 #ifdef MPPI_TRACE
     unsigned long long* trace;
@@ -204,9 +209,9 @@ constexpr int kCombineCols = 16;
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
 constexpr int kMaxRanks = 64;     // rank partials one combine block can hold (LDS xv[][16])
-constexpr int kSmallCombineNR = 24;   // up to 384 rows per split
-constexpr int kMaxSmallSplits = 8;    // row splits of the 256-thread combine (one poll batch)   // row loads in flight per lane of the 256-thread combine
-constexpr int kParamFloats = 32;   // LDS floats holding the problem constants in the fused rollout
+constexpr int kSmallCombineNR = 24;   // row loads in flight per lane of the 256-thread combine
+                                      // (16 row groups per block: up to 384 rows per split)
+constexpr int kMaxSmallSplits = 8;    // row splits of the 256-thread combine (one poll batch)
 
 // Group geometry by action dimension and the instantiated register-resident chunk lengths
 // (template NG = groups per lane); pick returns the smallest instantiated NG >= ng, 0 if none.
@@ -216,6 +221,10 @@ int rollout_max_groups(int A);
 int rollout_pick_ng_template(int A, int ng);
 size_t rollout_lds_bytes(int NBTp, int TAp);
 int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds);   // occupancy API, 0 = unknown
+// hipSuccess iff the code object of this library loads on the current device and holds the kernels
+// an engine of this act_dim launches (asked through hipFuncGetAttributes: an error code here,
+// where the first launch would abort inside the runtime)
+hipError_t probe_code_object(int A);
 
 // Optional dispatch timing: when both events are non-null the launch goes through
 // hipExtLaunchKernelGGL, which stamps the events with the dispatch packet's own start / end

@@ -109,6 +109,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
     P.B0 = to_vgpr(g.B0);
     P.dt2 = P.dt * P.dt;
     const long long k_cover = g.k_cover;
+    const unsigned int cover_and = g.cover_and;
     float* const cost_out = g.cost;
 
     // chunk geometry of this lane (same for every tile group)
@@ -228,7 +229,10 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                             all = all && have[j];
                         }
                         if (all) break;
-                        if (wall_clock64() - t0 > limit) { timed_out = true; break; }
+                        if (wall_clock64() - t0 > limit || watchdog_tripped(g.err_dev)) {
+                            timed_out = true;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(4);
                     }
 #pragma unroll
@@ -427,7 +431,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
             if (lane == 0) misc[4 + wave] = sw;
         }
         if (first) MPPI_STAMP(5);
-        const float wtN = ((long long)kglob < k_cover) ? wt : 0.0f;
+        const float wtN =
+            ((long long)kglob < k_cover && ((unsigned int)kglob & cover_and) == 0u) ? wt : 0.0f;
         float* wrow = wsum + wave * TAp + (c * nq) * 4;
         if constexpr (!EXACT) asm volatile("" : "+s"(ngs));
 #pragma unroll

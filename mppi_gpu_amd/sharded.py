@@ -82,6 +82,8 @@ class ShardedPointMassModel:
                                       torch.zeros(self.L * self.world, dtype=torch.float32).pin_memory())
         self.transport = "collective"
         self._validated = True
+        self.validated = None       # verdict of the "auto" check: True = direct reproduced the
+                                    # collective's bits on every rank, False = fell back
         if self._tstream is not None and transport != "collective":
             if self._open_direct():
                 self.transport = "direct"
@@ -150,6 +152,9 @@ class ShardedPointMassModel:
         if not self._all_ok(same):
             self.transport = "collective"
         self._validated = True
+        self.validated = self.transport == "direct"
+        self.validated = None       # verdict of the "auto" check: True = direct reproduced the
+                                    # collective's bits on every rank, False = fell back
 
     def memcpy_set_data(self, x, u, goal, w):
         if not self._validated:

@@ -162,3 +162,99 @@ def make_case(A, K, T, seed, u_scale=0.05, sigma=0.025):
     goal = np.array(PRESETS[A]["goal"], np.float32)
     w = np.array(PRESETS[A]["w"], np.float32)
     return dict(x0=x0, U=U, E=E, goal=goal, w=w, dt=np.float32(0.1))
+
+
+# ---- emulation of the reference's update_act launch structure ---------------
+# Test infrastructure: a literal restatement, block by block and tree level by tree level, of
+# update_act / update_act_kernel / sum_red_adim / copy_act (reference src/point_mass.cu:384-480,
+# 828-926, 668-741, 756-761) in float32, to pin which samples the reference's update covers for
+# act_dim != 2.  Only shapes without a racy in-place middle pass (first-level grid < 256*A).
+
+def _ref_tree(partial, A, B=256):
+    """In-block tree of both kernels (src/point_mass.cu:893-909, 709-725): `s > 1`, not `s > 0`."""
+    s = B * A // 2
+    while s > 1:
+        tids = np.arange(B)
+        act = tids[tids * A < s]
+        for j in range(A):      # threads run in lock step: read all, then write all
+            add = partial[act * A + j + s].copy()
+            partial[act * A + j] = (partial[act * A + j] + add).astype(np.float32)
+        s >>= 1
+    return partial
+
+
+def _ref_update_act_kernel(w, e_flat, T, t, A, n, grid, B=256):
+    v_r = np.zeros(grid * A, np.float32)
+    max_size = n * A * T
+    tids = np.arange(B)
+    for b in range(grid):
+        # shared memory holds B*A floats; the tree reads up to index B*A-1+... inside that range
+        partial = np.zeros(B * A, np.float32)
+        i = b * (B * 2) * A * T + t * A + tids * T * A
+        shift = B * T * A
+        k = b * B + tids + B * b
+        for j in range(A):
+            both = i + shift < max_size
+            one = (~both) & (i < max_size)
+            val = np.zeros(B, np.float32)
+            ib, kb = i[both], k[both]
+            val[both] = (w[kb] * e_flat[ib + j] + w[kb + B] * e_flat[ib + shift + j]).astype(np.float32)
+            io, ko = i[one], k[one]
+            val[one] = (w[ko] * e_flat[io + j]).astype(np.float32)
+            partial[tids * A + j] = val
+        partial = _ref_tree(partial, A, B)
+        v_r[b * A:(b + 1) * A] = partial[:A]
+    return v_r
+
+
+def _ref_sum_red_adim(v, n, A, grid, B=256):
+    out = v.copy()
+    tids = np.arange(B)
+    for b in range(grid):
+        partial = np.zeros(B * A, np.float32)
+        i = b * (B * 2) * A + tids * A
+        shift = B * A
+        for j in range(A):
+            both = i + shift < n * A
+            one = (~both) & (i < n * A)
+            val = np.zeros(B, np.float32)
+            val[both] = (v[i[both] + j] + v[i[both] + shift + j]).astype(np.float32)
+            val[one] = v[i[one] + j]
+            partial[tids * A + j] = val
+        partial = _ref_tree(partial, A, B)
+        out[b * A:(b + 1) * A] = partial[:A]
+    return out
+
+
+def ref_update_emulated(U, wts, E):
+    """U + what the reference's update_act adds, by its own launch structure (float32)."""
+    E = f32(E)
+    K, T, A = E.shape
+    B = 256
+    w = np.concatenate([f32(wts), np.zeros(2 * B, np.float32)])        # tail reads stay in bounds
+    e_flat = np.concatenate([E.reshape(-1), np.zeros(2 * B * T * A + A, np.float32)])
+    Uw = f32(U).reshape(T, A).copy()
+    grid1 = K // (B * A) + 1
+    assert grid1 < B * A, "shape has a racy in-place middle pass in the reference: not emulated"
+    for t in range(T):
+        v_r = _ref_update_act_kernel(w, e_flat, T, t, A, K, grid1, B)
+        if grid1 > 1:
+            n = grid1
+            v_pad = np.concatenate([v_r, np.zeros(2 * B * A, np.float32)])
+            v_r = _ref_sum_red_adim(v_pad, n, A, 1, B)
+        Uw[t] = (Uw[t] + v_r[:A]).astype(np.float32)
+    return Uw
+
+
+def ref_update_mask(K, A):
+    """Samples the reference's update sums (what ref_update_emulated reproduces): all for
+    act_dim 2; the first 512*(K/768+1) for act_dim 3; k even and -- with a second level, K >= 256
+    -- (k/512) even for act_dim 1."""
+    k = np.arange(K)
+    if A == 3:
+        return k < min(K, 512 * (K // 768 + 1))
+    if A == 1:
+        m = (k % 2) == 0
+        return m & ((k // 512) % 2 == 0) if K >= 256 else m
+    assert A == 2, "the reference has no 4-D system; its trees would also mix axes there"
+    return np.ones(K, bool)

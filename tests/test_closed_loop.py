@@ -97,6 +97,34 @@ def test_closed_loop_config5_meets_100hz_budget(gpu, tmp_path):
     assert rows[0].startswith("x,y,z,vx,vy,vz,ux,uy,uz,size_x,size_u") and len(rows) == steps + 2, len(rows)
 
 
+def test_driver_rejects_bad_dims_before_touching_anything(tmp_path):
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    for dims in ("0", "5", "-1"):
+        out = subprocess.run([exe, "--dims", dims], capture_output=True, text=True)
+        assert out.returncode == 2 and "--dims must be 1..4" in out.stderr
+    out = subprocess.run([exe, "--frobnicate", "1"], capture_output=True, text=True)
+    assert out.returncode == 2 and "unknown option" in out.stderr
+
+
+@pytest.mark.gpu
+def test_reference_flags_key_and_max_a(gpu, tmp_path):
+    """-k/--key (reference src/main.cu:417-423) is accepted and ignored; max-a is honoured only
+    when asked for (reference src/main.cu:524,566-568 parses it and drops it): with --max-a the
+    commanded actions stay inside the limit, without it they exceed it on the way to the goal."""
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    base = [exe, "-k", "../lib/contrib/mjkey.txt", "--dims", "2", "--samples", "4000", "--horizon",
+            "40", "--seconds", "0.6", "--noise", "0.25"]
+    peak = {}
+    for name, extra in (("free", []), ("limited", ["--max-a", "0.05"])):
+        traj = tmp_path / f"{name}.csv"
+        out = subprocess.run(base + extra + ["--traj-save", str(traj)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        rows = [r.split(",") for r in traj.read_text().strip().splitlines()[1:]]
+        u = np.array([[float(r[4]), float(r[5])] for r in rows if len(r) > 5 and r[4] != ""])
+        peak[name] = float(np.abs(u).max())
+    assert peak["limited"] <= 0.05 + 1e-6 < peak["free"], peak
+
+
 @pytest.mark.gpu
 def test_step_save_dump_matches_get_inf_columns(gpu, tmp_path):
     """-s/--step-save: the per-step dump (reference to_csv2 column order, generalised to A axes)

@@ -12,13 +12,21 @@ inputs.  Floating point, so tolerances are stated here:
   in the controls, which is the quantity the 1e-5 bar is stated on.)
                                                          (north_star: "controls ... to 1e-5 rel")
 The U criterion is |U_gpu - U_oracle|_inf <= 1e-5 * max(|U_oracle|_inf, sigma): element-wise
-relative error is meaningless where a control crosses zero.  The strict kernel meets it always.
-For the fused kernel the bar is max(that, 4 ulp(max cost)/lambda * max|E|): two correct fp32
+relative error is meaningless where a control crosses zero.  The strict kernel meets it always,
+and so does the fused (benchmarked) kernel wherever the weights average over enough samples:
+the PLAIN 1e-5 bar is asserted for every case whose effective sample size 1/sum(w^2) is at least
+ESS_PLAIN.  Only below that (nearly one-hot weights: the underflow and cost-ramp cases, tiny
+batches) the fused kernel gets max(that, 4 ulp(max cost)/lambda * max|E|): two correct fp32
 evaluations of a path cost of a few hundred differ by a few ulp (1.5e-5 each at 230), the
-weights by that amount RELATIVE, and when the weights are nearly one-hot (small effective sample
-size) nothing averages the difference out.  The same holds between the reference's own nvcc
-build (FMA-contracted) and its host arithmetic.
+weights by that amount RELATIVE, and with a handful of effective samples nothing averages the
+difference out.  The same holds between the reference's own nvcc build (FMA-contracted) and its
+host arithmetic.
+
+Every checked solve appends what it ACHIEVED (|dU|/scale, worst weight / cost rtol) to
+gpurun_out/parity_r02.json; the committed copy is profiles/parity_r02.json.
 """
+import atexit
+import json
 import os
 
 import numpy as np
@@ -40,7 +48,42 @@ def _model(gpu, A, K, T, case, chunks=0, strict=False, max_blocks=0):
     return m
 
 
+ESS_PLAIN = 32.0         # effective samples from which the fused kernel must meet the plain bar
+_RECORDS = []
+
+
+def _dump_records():
+    if not _RECORDS:
+        return
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_r02.json"), "w") as f:
+            json.dump({"bar": "|U_gpu - U_oracle|_inf / max(|U_oracle|_inf, sigma) <= 1e-5 "
+                              "(plain) wherever ess >= %g" % ESS_PLAIN,
+                       "cases": _RECORDS}, f, indent=1)
+    except OSError:
+        pass
+
+
+atexit.register(_dump_records)
+
+
 def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGMA):
+    wref = ref["weights"].astype(np.float64)
+    ess = float(1.0 / np.sum(wref * wref)) if wref.sum() > 0 else 0.0
+    scale0 = max(float(np.abs(ref["U"]).max()), SIGMA)
+    rec = {"case": tag, "kernel": "strict" if cost_exact else "fused", "K": int(ref["cost"].size),
+           "ess": round(ess, 1),
+           "dU_over_scale": float(np.abs(inf["u"] - ref["U"]).max() / scale0),
+           "dact_over_scale": float(np.abs(got_act - ref["next_act"]).max() / scale0),
+           "cost_rtol": float(np.max(np.abs(inf["cost"] - ref["cost"]) / np.abs(ref["cost"]))),
+           "weight_rtol": float(np.max(np.abs(inf["weight"] - ref["weights"])
+                                       / np.maximum(ref["weights"], 1e-30)
+                                       * (ref["weights"] > 1e-12))),
+           "nabla_rtol": float(abs(inf["nabla"] - ref["nabla"]) / ref["nabla"]),
+           "plain_bar": bool(cost_exact or ess >= ESS_PLAIN)}
+    _RECORDS.append(rec)
     if cost_exact:
         assert np.array_equal(inf["cost"], ref["cost"]), f"{tag}: cost not bit-exact"
         assert np.float32(inf["beta"]) == ref["beta"], tag
@@ -56,7 +99,7 @@ def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGM
                                atol=1e-12, err_msg=tag)
     scale = max(float(np.abs(ref["U"]).max()), SIGMA)
     tol = 1e-5 * scale
-    if not cost_exact:
+    if not cost_exact and ess < ESS_PLAIN:        # nearly one-hot weights only (module docstring)
         if "e" in inf:
             emax = float(np.abs(inf["e"]).max())
         tol = max(tol, 4 * float(np.spacing(np.float32(ref["cost"].max()))) / lam * emax)
@@ -436,16 +479,17 @@ def test_params_lambda_inv_s(gpu):
         _check_solve(act, inf, ref, cost_exact=strict, tag=f"params strict={strict}", lam=lam)
 
 
-def test_ref_compat_reproduces_a3_coverage_defect(gpu):
+@pytest.mark.parametrize("A,K,T,covered", [(3, 3000, 20, 2048), (1, 3000, 24, 768),
+                                             (1, 1000, 50, 256), (1, 200, 16, 100), (2, 900, 10, 900)])
+def test_ref_compat_reproduces_the_reference_update_coverage(gpu, A, K, T, covered):
     """with ref_compat the update sums only the samples the reference's
-    update_act covers for act_dim 3, while beta and nabla still use all K."""
-    A, K, T = 3, 3000, 20
+    update_act reaches (act_dim 3: the first 512*(K/768+1); act_dim 1: k even and (k/512) even;
+    act_dim 2: all), while beta and nabla still use all K.  The expected controls come from the
+    literal emulation of the reference's launch structure (oracle_lib.ref_update_emulated)."""
     c = ol.make_case(A, K, T, seed=77)
     full = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
-    cov = 2048
-    wts = full["weights"].copy()
-    wts[cov:] = 0
-    U_upd = ol.update(c["U"], wts, c["E"], f64=True)
+    assert int(ol.ref_update_mask(K, A).sum()) == covered
+    U_upd = ol.ref_update_emulated(c["U"], full["weights"], c["E"])
     with _model(gpu, A, K, T, c) as m:
         m.set_ref_compat(True)
         m.set_noise(c["E"])
@@ -455,8 +499,64 @@ def test_ref_compat_reproduces_a3_coverage_defect(gpu):
     scale = max(float(np.abs(U_upd).max()), SIGMA)
     assert np.abs(act - U_upd[0]).max() <= 1e-5 * scale
     assert np.abs(inf["u"][:-1] - U_upd[1:]).max() <= 1e-5 * scale
-    # and it does differ from the correct update
-    assert np.abs(inf["u"] - full["U"]).max() > 1e-6
+    # and it does differ from the correct update wherever the reference drops samples
+    if covered < K:
+        assert np.abs(inf["u"] - full["U"]).max() > 1e-6
+
+
+def test_action_limit_is_opt_in(gpu):
+    """max-a (reference src/main.cu:524,566-568: parsed, never applied): off by default; switched
+    on, every updated control is clamped to +-max_a[axis] and the returned action with it."""
+    A, K, T = 2, 1500, 40
+    c = ol.make_case(A, K, T, seed=91, u_scale=0.3)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    lim = np.array([0.2, 0.05], np.float32)
+    assert (np.abs(ref["U"]) > lim).any()
+    exp_U = np.clip(ref["U"], -lim, lim)
+    exp_act = np.clip(ref["next_act"], -lim, lim)
+    for strict in (False, True):
+        with _model(gpu, A, K, T, c, strict=strict) as m:
+            m.set_noise(c["E"])
+            m.set_action_limit(lim)
+            act = m.get_act()
+            U = m.get_u()
+            inside = np.abs(exp_U) < lim * 0.999
+            assert np.abs(U).max(axis=0)[0] <= lim[0] and np.abs(U).max(axis=0)[1] <= lim[1]
+            assert np.abs(U - exp_U)[inside].max() <= 1e-5 * max(float(np.abs(ref["U"]).max()), SIGMA)
+            assert np.abs(act - exp_act).max() <= 1e-5
+            # off again: the plain update
+            m.set_action_limit(None)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.set_noise(c["E"])
+            m.get_act()
+            assert np.abs(m.get_u() - ref["U"]).max() <= 1e-5 * max(float(np.abs(ref["U"]).max()), SIGMA)
+
+
+def test_device_time_out_is_sticky_until_set_data(gpu):
+    """A rank whose peer never shows up: the block that gave up publishes nothing, and every later
+    solve / read-out reports MPPI_ESTATE until mppi_set_data starts over."""
+    import torch
+    from mppi_gpu_amd import PointMassModel, MppiError
+    A, K, T = 2, 2000, 50
+    c = ol.make_case(A, K, T, seed=63)
+    with PointMassModel(K, T, float(c["dt"]), 2 * A, A) as m:
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        m.get_act()
+        U_before = m.get_u()
+        _, mine = m.xchg_open(0, 2)
+        W = ((T * A + 2 + 15) // 16) * 16
+        silent = torch.zeros(2 * 2 * W, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        m.xchg_connect(same_process=[mine, silent.data_ptr()])
+        m.xchg_set_timeout(0.2)
+        m.solve_exchange_async()
+        for call in (m.sync_act, m.get_u, m.get_act, m.solve_async, m.sync_act):
+            with pytest.raises(MppiError) as ei:
+                call()
+            assert ei.value.code == -4                      # MPPI_ESTATE, every time
+        m.memcpy_set_data(c["x0"], U_before, c["goal"], c["w"])      # starts over
+        assert np.array_equal(m.get_u(), U_before)
+        assert np.all(np.isfinite(m.get_act()))
 
 
 def test_sharded_engines_equal_single_engine(gpu):
@@ -553,20 +653,36 @@ def test_direct_exchange_in_process_equals_gathered_finish(gpu):
         s.xchg_connect(same_process=ptrs)
         s.xchg_set_timeout(3.0)
 
+    # The kernels wait for one another, so they must RUN together; engines of one process can
+    # share a hardware queue (HIP multiplexes streams onto a few), which serialises them.  That is
+    # a property of this single-process arrangement, not of the exchange (one process per GPU in
+    # production; the multi-process tests cover that).  Whether these two streams run kernels
+    # side by side is PROBED first: only if they do not, a time-out below is a skip.
+    def streams_run_concurrently():
+        e_long, e_short = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(streams[0]):
+            torch.cuda._sleep(400_000_000)          # ~0.2 s of spinning on stream 0
+            e_long.record()
+        with torch.cuda.stream(streams[1]):
+            torch.zeros(8, device="cuda").add_(1)
+            e_short.record()
+        e_short.synchronize()
+        side_by_side = not e_long.query()
+        torch.cuda.synchronize()
+        return side_by_side
+
+    co_scheduled = streams_run_concurrently()
+
     def sync_all():
-        # The kernels wait for one another, so they must RUN together; engines of one
-        # process can share a hardware queue (HIP multiplexes streams onto a few), which
-        # serialises them.  That is a property of this single-process arrangement, not of the
-        # exchange (one process per GPU in production; the multi-process tests cover that).
         try:
             return [s.sync_act() for s in eng]
         except RuntimeError as err:
-            if "timed out" in str(err):
+            if "timed out" in str(err) and not co_scheduled:
                 for s in eng:
                     s.close()
-                pytest.skip("the engines' streams share a hardware queue in this process: "
+                pytest.skip("probe: the two streams share a hardware queue in this process, "
                             "their kernels cannot be co-scheduled")
-            raise
+            raise                 # co-scheduled streams and still a time-out: a real failure
 
     for it in range(3):
         for s, st in zip(eng, streams):
@@ -618,12 +734,22 @@ def test_direct_exchange_times_out_instead_of_hanging(gpu):
 
 # ---- BASELINE.json full sizes: size-independent properties + oracle on the device's noise ----
 
-FULL = [(2, 10_000, 200), (3, 100_000, 200)]
+# (A, K, T, k_offset): configs 2 and 3, config 4 whole on one GPU (2.4 GB of noise, 64-bit tile
+# offsets) and config 4's LAST of eight shards (global sample indices 875 000 .. 999 999)
+FULL = [(2, 10_000, 200, None), (3, 100_000, 200, None), (3, 1_000_000, 200, None),
+        (3, 125_000, 200, 875_000)]
 
 
-@pytest.mark.parametrize("A,K,T", FULL)
-def test_full_size_parity_and_properties(gpu, A, K, T):
+@pytest.mark.parametrize("A,K,T,k_offset", FULL)
+def test_full_size_parity_and_properties(gpu, A, K, T, k_offset):
+    from mppi_gpu_amd import PointMassModel
     c = ol.make_case(A, 1, T, seed=300 + A, u_scale=0.02)
+
+    def _model(gpu, A, K, T, c):          # a shard engine when the case names an offset
+        m = PointMassModel(K, T, float(c["dt"]), 2 * A, A, k_offset=k_offset)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        return m
+
     with _model(gpu, A, K, T, c) as m:
         m.set_seed(42)
         m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
@@ -632,7 +758,12 @@ def test_full_size_parity_and_properties(gpu, A, K, T):
         geo = m.geometry()
     # (1) the oracle, run on the very noise the device drew, reproduces the solve
     ref = ol.solve(c["x0"], c["U"], inf["e"], c["goal"], c["w"], c["dt"])
-    _check_solve(act, inf, ref, cost_exact=False, tag=f"full A{A} K{K} {geo}")
+    _check_solve(act, inf, ref, cost_exact=False, tag=f"full A{A} K{K} off={k_offset} {geo}")
+    if k_offset is not None:
+        # the shard draws the noise of the GLOBAL sample indices: rows 0..63 of the shard are
+        # rows k_offset.. of the host statement of the stream
+        h = ol.noise(42, 0, k_offset, 64, T, A, [SIGMA] * A)
+        np.testing.assert_allclose(inf["e"][:64], h, rtol=0, atol=SIGMA * 2e-5)
     # (2) weights are a probability vector
     assert np.isclose(inf["weight"].astype(np.float64).sum(), 1.0, atol=2e-5)
     assert inf["weight"].min() >= 0 and np.isclose(inf["weight"].max(), 1.0 / inf["nabla"], rtol=1e-5)

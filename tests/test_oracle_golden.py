@@ -187,3 +187,27 @@ def test_hw_box_muller_restatement_agrees_with_rocrand_normal4():
         mine = ol.noise(99, 0, k, 1, 100, 1, [1.0])[0, 12:16, 0]      # block 3 = normals 12..15
         worst = max(worst, float(np.abs(np.array(list(out), np.float32) - mine).max()))
     assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("A,K,T,covered", [(1, 100, 7, 50), (1, 255, 5, 128), (1, 256, 5, 128),
+                                           (1, 1000, 6, 256), (1, 3000, 4, 768), (2, 700, 5, 700),
+                                           (2, 3000, 3, 3000), (3, 700, 5, 512), (3, 1000, 3, 1000),
+                                           (3, 3000, 4, 2048)])
+def test_reference_update_launch_structure_covers_what_the_masks_say(A, K, T, covered):
+    """the literal emulation of the reference's update_act launches (grid sizes,
+    512 samples per block, block trees that stop at s > 1; src/point_mass.cu:384-480,668-741,
+    828-926) sums exactly the samples of oracle_lib.ref_update_mask -- K=1000 -> 256 and
+    K=3000 -> 768 for act_dim 1, 3000 -> 2048 for act_dim 3, everything for act_dim 2 -- which
+    is what ref_compat reproduces on the GPU."""
+    rng = np.random.default_rng(K + A)
+    E = (rng.standard_normal((K, T, A)) * 0.025).astype(np.float32)
+    w = rng.random(K).astype(np.float32)
+    w /= w.sum()
+    U = (rng.standard_normal((T, A)) * 0.05).astype(np.float32)
+    mask = ol.ref_update_mask(K, A)
+    assert int(mask.sum()) == covered
+    emu = ol.ref_update_emulated(U, w, E)
+    masked = ol.update(U, np.where(mask, w, 0).astype(np.float32), E, f64=True)
+    assert np.abs(emu - masked).max() <= 2e-8
+    if covered < K:
+        assert np.abs(emu - ol.update(U, w, E, f64=True)).max() > 1e-5
