@@ -164,6 +164,8 @@ def main():
                          "runs are not measured at idle clocks (0 = off)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--packing", type=int, default=0,
+                    help="mppi_set_packing: 0 auto, -1 row-aligned kernel only, n packed with n groups per lane")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--strict", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,6 +233,8 @@ def main():
         m = sharded.engine          # this rank's shard: samples [rank*K, (rank+1)*K)
     m.set_pipeline(args.pipeline)
     m.set_tuning(chunks=args.chunks, strict=args.strict, max_blocks=args.max_blocks)
+    if args.packing:
+        m.set_packing(args.packing)
     m.set_seed(0)
     (sharded or m).memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
     geo = m.geometry()
@@ -282,11 +286,12 @@ def main():
     roof = None
     # mode 0 lets the combine ride in the next rollout launch while launches are short (at most two
     # tiles per block, engine.hip enqueue_rollout); longer ones launch it on its own
-    n_tiles = -(-K * geo["chunks"] // geo["block"])
+    n_tiles = geo["tile_groups"]
     riding = (args.pipeline == 0 and not args.strict and not args.blocking
               and n_tiles <= 2 * geo["grid"])
     kind = "ride" if riding else "plain"
-    prof_key = f"{args.workload}:chunks={geo['chunks']}:{kind}"
+    shape = f"packed{geo['groups_per_lane']}" if geo["packed"] else f"chunks={geo['chunks']}"
+    prof_key = f"{args.workload}:{shape}:{kind}"
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
@@ -304,9 +309,11 @@ def main():
                 traffic_src = (f"committed profile profiles/{PROFILE_TRAFFIC} (rocprofv3 --pmc "
                                "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command); not "
                                "measured in this run")
+        base = "k_rollout_packed" if geo["packed"] else "k_rollout_fused"
         kname = ("k_rollout_stream" if geo["strict"] else
-                 "k_rollout_ride (rollout of solve j + combine of solve j-1 in one launch)" if riding
-                 else "k_rollout_fused")
+                 (base + "_ride" if geo["packed"] else "k_rollout_ride")
+                 + " (rollout of solve j + combine of solve j-1 in one launch)" if riding
+                 else base)
         roof = {"bound": "hbm", "kernel": kname,
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

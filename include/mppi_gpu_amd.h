@@ -115,6 +115,17 @@ int mppi_set_action_limit(mppi_engine* e, const float* max_a);
  * anchor.  max_blocks caps the persistent grid (0 = auto). */
 int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
 
+/* Trajectory packing of the fused rollout.  By default (0) the engine lays whole trajectories
+ * end to end over the lanes of a wavefront (a trajectory need not fill a power-of-two number of
+ * lanes: T = 200, act_dim 3 uses 97.7 % of the lane-slots instead of 78 %) whenever that wastes
+ * fewer slots than `chunks` lanes per trajectory would; needs T a multiple of the group length
+ * (4, 2, 4, 1 steps for act_dim 1..4), cost weights >= 0 and chunks == 0.  -1 = never (the
+ * row-aligned kernel mppi_set_tuning describes), n > 0 = packed with n groups per lane
+ * (MPPI_EINVAL if that size is not built or the problem does not qualify). */
+int mppi_set_packing(mppi_engine* e, int groups_per_lane);
+/* out = { packed (0/1), groups per lane, trajectories per wavefront, tile groups of 4 wavefronts } */
+int mppi_get_layout(mppi_engine* e, int out[4]);
+
 /* How consecutive solves are enqueued:
  *   0  deferred combine (default).  mppi_solve_async launches the rollout only; the combine
  *      (beta, nabla, update, shift, action) is launched by whatever comes next: if that is another

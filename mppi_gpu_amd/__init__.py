@@ -171,6 +171,10 @@ class PointMassModel:
     def set_tuning(self, chunks=0, strict=False, max_blocks=0):
         check(self._lib.mppi_set_tuning(self._h, int(chunks), int(bool(strict)), int(max_blocks)))
 
+    def set_packing(self, groups_per_lane):
+        """0 auto (default), -1 never, n > 0 force the packed kernel with n groups per lane."""
+        check(self._lib.mppi_set_packing(self._h, int(groups_per_lane)))
+
     def set_pipeline(self, mode):
         """0 deferred combine (default), 1 eager; see the header."""
         check(self._lib.mppi_set_pipeline(self._h, int(mode)))
@@ -178,7 +182,11 @@ class PointMassModel:
     def geometry(self):
         g = (C.c_int * 5)()
         check(self._lib.mppi_get_geometry(self._h, g))
-        return {"chunks": g[0], "nq": g[1], "grid": g[2], "block": g[3], "strict": bool(g[4])}
+        lay = (C.c_int * 4)()
+        check(self._lib.mppi_get_layout(self._h, lay))
+        return {"chunks": g[0], "nq": g[1], "grid": g[2], "block": g[3], "strict": bool(g[4]),
+                "packed": bool(lay[0]), "groups_per_lane": lay[1], "trajectories_per_wave": lay[2],
+                "tile_groups": lay[3]}
 
     # -- asynchronous / sharded ---------------------------------------------------------------
     def solve_async(self, stream=None):

@@ -157,6 +157,73 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float
     }
 }
 
+// Rollout side of a riding combine (DeferredCombine): the combine-role blocks of this very launch
+// are producing this solve's controls; take them from the tagged words the applying blocks
+// publish, one value per thread and sweep and four words in flight per thread, polling what is not
+// there yet (bounded; cut short when the watchdog word is already set), and stage them -- with
+// lambda*inv_s*u -- into LDS as one float4 per Philox block (n_blocks blocks, zero padded).
+template <int A>
+__device__ __forceinline__ void ride_fetch_controls(const RolloutArgs& g, const DeferredCombine& d,
+                                                    float lambda, float4* ulds, float4* uclds,
+                                                    int n_blocks, int TA)
+{
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long limit = g.ride_timeout_ticks;
+    bool timed_out = false;
+    float* uflat = reinterpret_cast<float*>(ulds);
+    float* ucflat = reinterpret_cast<float*>(uclds);
+    const unsigned long long* fin_p = g.fin_tag;
+    const unsigned int tag_want = d.c.tag;
+    constexpr int kBatch = 4;      // words in flight per thread: one round trip, not four
+    for (int base = threadIdx.x; base < n_blocks * 4; base += kBatch * kRolloutThreads) {
+        float unew[kBatch];
+        bool have[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            unew[j] = 0.0f;
+            have[j] = base + j * kRolloutThreads >= TA;     // padding: nothing to fetch
+        }
+        for (;;) {
+            unsigned long long w[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int idx = base + j * kRolloutThreads;
+                const int n = (idx < TA - A) ? idx + A : idx;  // shift; last step repeats
+                w[j] = have[j] ? 0ull
+                               : __hip_atomic_load(fin_p + n, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool all = true;
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                if (!have[j] && (unsigned int)(w[j] >> 32) == tag_want) {
+                    unew[j] = __uint_as_float((unsigned int)w[j]);
+                    have[j] = true;
+                }
+                all = all && have[j];
+            }
+            if (all) break;
+            if (wall_clock64() - t0 > limit || watchdog_tripped(g.err_dev)) {
+                timed_out = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int idx = base + j * kRolloutThreads;
+            if (idx < n_blocks * 4) {
+                uflat[idx] = unew[j];
+                ucflat[idx] = lambda * (unew[j] * g.inv_s[idx % A]);
+            }
+        }
+    }
+    if (timed_out) {     // device watchdog word, reported by the next call on the engine
+        *g.err_dev = 2;
+        if (g.err_host) *g.err_host = 2;
+    }
+}
+
 // One combine block: column block cb = bid % n_cols, row split rs = bid / n_cols.
 template <int THREADS, int NR>    // NR row loads in flight per lane
 __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, const CombineSmem& sm)

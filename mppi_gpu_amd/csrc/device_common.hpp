@@ -352,5 +352,30 @@ __device__ __forceinline__ void stage_controls(const RolloutArgs& g, unsigned lo
     }
 }
 
+__device__ __forceinline__ float to_vgpr(float x)
+{   // opaque move: afterwards the compiler no longer knows the value is wave-uniform
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// nominal controls AND lambda*inv_s*controls into LDS, one float4 per Philox block each, zero
+// padded past T*A (n_blocks blocks are staged)
+template <int A>
+__device__ __forceinline__ void stage_controls_pair(const RolloutArgs& g, const float* Uin,
+                                                    float lambda, float4* ulds, float4* uclds,
+                                                    int n_blocks, int TA)
+{
+    for (int b = threadIdx.x; b < n_blocks; b += kRolloutThreads) {
+        float u[4], uc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = b * 4 + i;
+            u[i] = (n < TA) ? Uin[n] : 0.0f;
+            uc[i] = lambda * (u[i] * g.inv_s[(b * 4 + i) % A]);
+        }
+        ulds[b] = make_float4(u[0], u[1], u[2], u[3]);
+        uclds[b] = make_float4(uc[0], uc[1], uc[2], uc[3]);
+    }
+}
 
 }  // namespace mppi

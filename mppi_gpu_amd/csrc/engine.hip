@@ -96,11 +96,14 @@ struct mppi_engine {
 
     // geometry
     int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
+    int user_packing = 0;       // 0 auto, -1 never, NG > 0: packed kernel with NG groups per lane
     bool geom_ok = false;
     int C = 1, logC = 0, ng = 0, nq = 0, NGt = 0, L = 0, c_last = 0, n_last = 0, NBTp = 0;
     int n_tileblk = 0, grid = 0, strict = 0;
+    bool packed = false;        // packed layout (rollout_packed_impl.hpp): ng groups per lane,
+    int TPW = 0;                // TPW trajectories per wavefront, NGT groups per trajectory
     // geometry the stored noise / partials belong to
-    int last_C = 1, last_nq = 0;
+    mppi::ELayout last_lay = {0, 1, 0, 0, 0, 0};
     unsigned long long last_idx = 0;
 
     // device memory
@@ -215,15 +218,50 @@ int ensure_geometry(mppi_engine_t* e)
         NGt = mppi::rollout_pick_ng_template(e->A, ng);
         if (!NGt) return fail(MPPI_EINVAL, "no kernel for %d groups per lane", ng);
     }
+    // Packed layout (rollout_packed_impl.hpp): whole trajectories end to end over the lanes of a
+    // wavefront.  Needs a horizon of whole groups and non-negative cost weights; taken when it
+    // wastes fewer group slots than the power-of-two lanes per trajectory above (or when forced).
+    bool packed = false;
+    int pk_NG = 0, TPW = 0;
+    if (!strict && e->user_packing >= 0 && (e->user_chunks == 0 || e->user_packing > 0)) {
+        bool w_ok = true;
+        for (int i = 0; i < e->S; ++i) w_ok = w_ok && e->w[i] >= 0.f;
+        const bool whole = e->T % e->SG == 0;
+        double best = 0.0;
+        for (const int* cand = mppi::packed_ng_list(e->A); *cand; ++cand) {
+            const int n = *cand;
+            if (e->user_packing > 0 && n != e->user_packing) continue;
+            if (!whole || !w_ok || NGT < n || NGT > 64 * n) continue;
+            const int tpw = 64 * n / NGT;
+            const double util = (double)tpw * NGT / (64.0 * n);
+            if (util > best + 1e-9) { best = util; pk_NG = n; TPW = tpw; }
+        }
+        if (e->user_packing > 0 && !pk_NG)
+            return fail(MPPI_EINVAL, "packed kernel with %d groups per lane not available for "
+                        "T=%d act_dim=%d (needs T %% %d == 0, weights >= 0, an instantiated size)",
+                        e->user_packing, e->T, e->A, e->SG);
+        const double util_row = (double)NGT / ((double)C * ng);
+        packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
+        if (packed && e->user_packing <= 0 &&
+            mppi::packed_lds_bytes(e->A, pk_NG, e->NBT, TPW) > 64 * 1024)
+            packed = false;          // horizon too long for the LDS slots: row-aligned kernel
+    }
+    if (packed) {
+        C = 1;                      // (unused by the packed kernel)
+        ng = pk_NG;
+        NGt = pk_NG;
+    }
     const int nq = ng * e->BPG;
     const int L = ng * e->SG;
     const int c_last = (e->T - 1) / L;
     const int n_last = e->T - c_last * L;
-    const int NBTp = (C * nq > e->NBT) ? C * nq : e->NBT;
+    const int NBTp = packed ? e->NBT : ((C * nq > e->NBT) ? C * nq : e->NBT);
     const long long lanes = (long long)e->K * C;
-    const long long ntb = (lanes + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
+    const long long ntb = packed ? (((long long)e->K + TPW - 1) / TPW + 3) / 4
+                                 : (lanes + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
     if (ntb > 0x7fffffffLL) return fail(MPPI_EINVAL, "too many samples");
-    const size_t lds_need = mppi::rollout_lds_bytes(NBTp, C * nq * 4);
+    const size_t lds_need = packed ? mppi::packed_lds_bytes(e->A, pk_NG, e->NBT, TPW)
+                                   : mppi::rollout_lds_bytes(NBTp, C * nq * 4);
     int max_blocks = e->user_max_blocks;
     if (max_blocks <= 0) {
         // persistent grid = 3 x what the chip holds at once (blocks per CU from the occupancy
@@ -235,19 +273,23 @@ int ensure_geometry(mppi_engine_t* e)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             ncu = prop.multiProcessorCount;
         const bool in_kernel_sampling = !e->injected;
-        const int per_cu = strict ? 0 : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
-        max_blocks = per_cu > 0 ? 3 * per_cu * ncu : 2048;
+        const int per_cu = strict ? 0
+                           : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need)
+                                    : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
+        // (the packed kernel's blocks meet only once, at their end: one round of resident blocks
+        //  walking all tiles is best, measured 81 us at 512 blocks against 87 at 1536, C3)
+        max_blocks = per_cu > 0 ? (packed ? 1 : 3) * per_cu * ncu : 2048;
         if (max_blocks > 3072) max_blocks = 3072;
     }
     if (max_blocks > mppi::kMaxParts) max_blocks = mppi::kMaxParts;
     const int grid = (int)(ntb < max_blocks ? ntb : max_blocks);
 
-    const size_t lds = mppi::rollout_lds_bytes(NBTp, C * nq * 4);
+    const size_t lds = lds_need;
     if (lds > 64 * 1024)
         return fail(MPPI_EINVAL, "LDS need %zu B exceeds 64 KiB (T=%d A=%d C=%d)", lds, e->T, e->A,
                     C);
 
-    const size_t need = (size_t)ntb * 4 * nq * 64 * 4;
+    const size_t need = (size_t)ntb * 4 * nq * 64 * 4;      // 4 wavefront tiles per tile group
     if (need > e->eint_floats) {
         if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
         e->d_Eint = nullptr;
@@ -278,6 +320,8 @@ int ensure_geometry(mppi_engine_t* e)
     e->n_last = n_last;
     e->NBTp = NBTp;
     e->strict = strict;
+    e->packed = packed;
+    e->TPW = TPW;
     e->n_tileblk = (int)ntb;
     e->grid = grid;
     e->geom_ok = true;
@@ -338,6 +382,26 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.c_last = e->c_last;
     a.n_last = e->n_last;
     a.n_tileblk = e->n_tileblk;
+    a.packed = e->packed ? 1 : 0;
+    a.NGT = e->NGT;
+    a.TPW = e->TPW;
+    a.pk_has_cg = 0;
+    for (int i = 0; i < e->A; ++i) {
+        // scaled state of the packed kernel: d_p = sp (p - g_p), d_v = sv (v - g_v); a zero weight
+        // gets the scale 2^-60, whose square vanishes against any cost (and is exact to undo)
+        const double wp = e->w[i], wv = e->w[e->A + i], gp = e->goal[i], gv = e->goal[e->A + i];
+        const double sp = wp > 0.0 ? sqrt(wp) : ldexp(1.0, -60);
+        const double sv = wv > 0.0 ? sqrt(wv) : ldexp(1.0, -60);
+        a.pk_sp[i] = (float)sp;
+        a.pk_sv[i] = (float)sv;
+        a.pk_k1[i] = (float)(sp * (double)e->dt / sv);
+        a.pk_k2[i] = (float)(sp * (double)e->B0);
+        a.pk_k3[i] = (float)(sv * (double)e->dt);
+        a.pk_cg[i] = (float)(sp * (double)e->dt * gv);
+        a.pk_gps[i] = (float)(sp * gp);
+        a.pk_gvs[i] = (float)(sv * gv);
+        if (gv != 0.0) a.pk_has_cg = 1;
+    }
     a.dt = e->dt;
     a.B0 = e->B0;
     a.lambda = e->lambda;
@@ -506,8 +570,9 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         }
     }
     e->last_stream = st;
+    const mppi::ELayout lay = {e->packed ? 1 : 0, e->C, e->nq, e->ng, e->NGT, e->TPW};
     if (e->injected && e->inj_dirty) {
-        HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, e->C, e->nq, st));
+        HIPCHK(mppi::launch_import_noise(e->A, e->d_Einj, e->d_Eint, e->K, e->T, lay, st));
         e->inj_dirty = false;
     }
     float* Ecur = e->d_Eint;
@@ -549,11 +614,12 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     const bool sample_in_kernel = !e->injected;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
+    else if (e->packed)
+        HIPCHK(mppi::launch_rollout_packed(e->A, e->ng, sample_in_kernel, e->grid, ra, dc, st, tm));
     else
         HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, sample_in_kernel, e->grid, ra, dc, st, tm));
     e->last_E = Ecur;
-    e->last_C = e->C;
-    e->last_nq = e->nq;
+    e->last_lay = lay;
     e->last_idx = e->solve_idx;
     memcpy(e->x0_last, e->x0, sizeof e->x0);
     return MPPI_OK;
@@ -761,6 +827,11 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
         int rc_ = clear_watchdog(e);
         if (rc_) return rc_;
     }
+    {   // the packed kernel needs weights >= 0: a change of their sign pattern re-plans the launch
+        bool was = true, now = true;
+        for (int i = 0; i < e->S; ++i) { was = was && e->w[i] >= 0.f; now = now && w[i] >= 0.f; }
+        if (was != now) e->geom_ok = false;
+    }
     for (int i = 0; i < e->S; ++i) { e->x0[i] = x0[i]; e->goal[i] = goal[i]; e->w[i] = w[i]; }
     e->args_valid = false;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
@@ -913,8 +984,8 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     if (noise) {
         const size_t n = (size_t)e->K * e->T * e->A;
         if ((rc = ensure_scratch(e, n))) return rc;
-        HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_C,
-                                         e->last_nq, e->stream));
+        HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_lay,
+                                         e->stream));
         {
         int rc_ = settle(e);
         if (rc_) return rc_;
@@ -928,8 +999,8 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         float* d_x0 = e->d_scratch + n;
         HIPCHK(hipMemcpy(d_x0, e->x0_last, 8 * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(mppi::launch_trace_states(e->A, e->last_E, e->d_U + (e->last_idx & 1ull) * e->TA,
-                                         d_x0, e->d_scratch, e->K, e->T, e->last_C, e->last_nq,
-                                         e->dt, e->B0, e->stream));
+                                         d_x0, e->d_scratch, e->K, e->T, e->last_lay, e->dt, e->B0,
+                                         e->stream));
         {
         int rc_ = settle(e);
         if (rc_) return rc_;
@@ -1035,6 +1106,37 @@ int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks)
     int rc = ensure_geometry(e);
     if (rc) e->geom_ok = false;
     return rc;
+}
+
+int mppi_set_packing(mppi_engine* e, int groups_per_lane)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (groups_per_lane < -1) return fail(MPPI_EINVAL, "groups_per_lane must be >= -1");
+    {
+        int rc_ = settle(e);
+        if (rc_) return rc_;
+    }
+    const int was = e->user_packing;
+    e->user_packing = groups_per_lane;
+    e->geom_ok = false;
+    int rc = ensure_geometry(e);
+    if (rc) {
+        e->user_packing = was;
+        e->geom_ok = false;
+    }
+    return rc;
+}
+
+int mppi_get_layout(mppi_engine* e, int out[4])
+{
+    if (!e || !out) return fail(MPPI_EINVAL, "null argument");
+    int rc = ensure_geometry(e);
+    if (rc) return rc;
+    out[0] = e->packed ? 1 : 0;
+    out[1] = e->ng;
+    out[2] = e->packed ? e->TPW : 64 / e->C;
+    out[3] = e->n_tileblk;
+    return MPPI_OK;
 }
 
 int mppi_set_pipeline(mppi_engine* e, int on)
@@ -1262,7 +1364,7 @@ int mppi_get_geometry(mppi_engine* e, int out[5])
     if (!e || !out) return fail(MPPI_EINVAL, "null argument");
     int rc = ensure_geometry(e);
     if (rc) return rc;
-    out[0] = e->C; out[1] = e->nq; out[2] = e->grid; out[3] = mppi::kRolloutThreads;
+    out[0] = e->packed ? 0 : e->C; out[1] = e->nq; out[2] = e->grid; out[3] = mppi::kRolloutThreads;
     out[4] = e->strict;
     return MPPI_OK;
 }

@@ -184,20 +184,30 @@ k_finish_gathered(const CombineArgs a, const float* __restrict__ gathered, int G
 // Off-path kernels: layout conversion, state trace, normalised weights (debug / get_inf).
 // ------------------------------------------------------------------------------------------
 template <int A>
-__device__ __forceinline__ size_t eint_index(long long kloc, int t, int a, int C, int nq)
+__device__ __forceinline__ size_t eint_index(long long kloc, int t, int a, const ELayout& L)
 {
     const int n = t * A + a;         // flat normal index of the sample
     const int b = n >> 2;            // Philox block
-    const int c = b / nq;
-    const int q = b - c * nq;
-    const long long gid = kloc * C + c;
+    if (L.packed) {
+        constexpr int BPG = Dim<A>::BPG;
+        const long long tile = kloc / L.TPW;                  // one wavefront = TPW trajectories
+        const int j = (int)(kloc - tile * L.TPW);
+        const int r = b / BPG;                                // group of the trajectory
+        const int s = j * L.NGT + r;                          // group slot of the wavefront
+        const int lane = s / L.NG;
+        const int q = (s - lane * L.NG) * BPG + (b - r * BPG);
+        return (((size_t)tile * L.nq + q) * 64 + lane) * 4 + (n & 3);
+    }
+    const int c = b / L.nq;
+    const int q = b - c * L.nq;
+    const long long gid = kloc * L.C + c;
     const size_t tile = (size_t)(gid >> 6);
     const int lane = (int)(gid & 63);
-    return ((tile * nq + q) * 64 + lane) * 4 + (n & 3);
+    return ((tile * L.nq + q) * 64 + lane) * 4 + (n & 3);
 }
 
 template <int A>
-__global__ void k_export_noise(const float* Eint, float* E, int K, int T, int C, int nq)
+__global__ void k_export_noise(const float* Eint, float* E, int K, int T, const ELayout L)
 {
     const size_t total = (size_t)K * T * A;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -206,12 +216,12 @@ __global__ void k_export_noise(const float* Eint, float* E, int K, int T, int C,
         const size_t kt = idx / A;
         const int t = (int)(kt % T);
         const long long k = (long long)(kt / T);
-        E[idx] = Eint[eint_index<A>(k, t, a, C, nq)];
+        E[idx] = Eint[eint_index<A>(k, t, a, L)];
     }
 }
 
 template <int A>
-__global__ void k_import_noise(const float* E, float* Eint, int K, int T, int C, int nq)
+__global__ void k_import_noise(const float* E, float* Eint, int K, int T, const ELayout L)
 {
     const size_t total = (size_t)K * T * A;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -220,7 +230,7 @@ __global__ void k_import_noise(const float* E, float* Eint, int K, int T, int C,
         const size_t kt = idx / A;
         const int t = (int)(kt % T);
         const long long k = (long long)(kt / T);
-        Eint[eint_index<A>(k, t, a, C, nq)] = E[idx];
+        Eint[eint_index<A>(k, t, a, L)] = E[idx];
     }
 }
 
@@ -228,7 +238,7 @@ __global__ void k_import_noise(const float* E, float* Eint, int K, int T, int C,
 // rollout used (reference layout of _x, src/point_mass.cu:63).
 template <int A>
 __global__ void k_trace_states(const float* Eint, const float* U, const float* x0, float* X,
-                               int K, int T, int C, int nq, float dt, float B0)
+                               int K, int T, const ELayout L, float dt, float B0)
 {
     constexpr int S = 2 * A;
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,7 +257,7 @@ __global__ void k_trace_states(const float* Eint, const float* U, const float* x
 #pragma unroll
         for (int i = 0; i < A; ++i) {
             u[i] = U[t * A + i];
-            e[i] = Eint[eint_index<A>(k, t, i, C, nq)];
+            e[i] = Eint[eint_index<A>(k, t, i, L)];
         }
         lti_step<A>(p, v, u, e, dt, B0);
 #pragma unroll
@@ -306,6 +316,72 @@ extern template int fused_blocks_per_cu_a<1>(int, bool, size_t);
 extern template int fused_blocks_per_cu_a<2>(int, bool, size_t);
 extern template int fused_blocks_per_cu_a<3>(int, bool, size_t);
 extern template int fused_blocks_per_cu_a<4>(int, bool, size_t);
+
+// ---- packed rollout (rollout_packed_impl.hpp, instantiated in rollout_packed_a{1,2,3,4}.hip) ----
+template <int A>
+hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
+                           const DeferredCombine& d, hipStream_t st, LaunchTiming tm);
+template <int A>
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds);
+template <int A>
+size_t packed_lds_bytes_a(int NG, int NBT, int TPW);
+#define MPPI_PACKED_EXTERN(A_)                                                                       \
+    extern template hipError_t launch_packed_a<A_>(int, bool, int, const RolloutArgs&,               \
+                                                   const DeferredCombine&, hipStream_t, LaunchTiming); \
+    extern template int packed_blocks_per_cu_a<A_>(int, bool, size_t);                               \
+    extern template size_t packed_lds_bytes_a<A_>(int, int, int);
+MPPI_PACKED_EXTERN(1)
+MPPI_PACKED_EXTERN(2)
+MPPI_PACKED_EXTERN(3)
+MPPI_PACKED_EXTERN(4)
+#undef MPPI_PACKED_EXTERN
+
+// groups-per-lane values the packed kernel is instantiated for (rollout_packed_impl.hpp: PackedNG)
+const int* packed_ng_list(int A)
+{
+    static const int l1[] = {4, 0}, l2[] = {5, 8, 0}, l3[] = {4, 0}, l4[] = {10, 0}, none[] = {0};
+    switch (A) {
+        case 1: return l1;
+        case 2: return l2;
+        case 3: return l3;
+        case 4: return l4;
+        default: return none;
+    }
+}
+
+size_t packed_lds_bytes(int A, int NG, int NBT, int TPW)
+{
+    switch (A) {
+        case 1: return packed_lds_bytes_a<1>(NG, NBT, TPW);
+        case 2: return packed_lds_bytes_a<2>(NG, NBT, TPW);
+        case 3: return packed_lds_bytes_a<3>(NG, NBT, TPW);
+        case 4: return packed_lds_bytes_a<4>(NG, NBT, TPW);
+        default: return 0;
+    }
+}
+
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds)
+{
+    switch (A) {
+        case 1: return packed_blocks_per_cu_a<1>(NG, sample, lds);
+        case 2: return packed_blocks_per_cu_a<2>(NG, sample, lds);
+        case 3: return packed_blocks_per_cu_a<3>(NG, sample, lds);
+        case 4: return packed_blocks_per_cu_a<4>(NG, sample, lds);
+        default: return 0;
+    }
+}
+
+hipError_t launch_rollout_packed(int A, int NG, bool sample, int grid, const RolloutArgs& a,
+                                 const DeferredCombine& d, hipStream_t st, LaunchTiming tm)
+{
+    switch (A) {
+        case 1: return launch_packed_a<1>(NG, sample, grid, a, d, st, tm);
+        case 2: return launch_packed_a<2>(NG, sample, grid, a, d, st, tm);
+        case 3: return launch_packed_a<3>(NG, sample, grid, a, d, st, tm);
+        case 4: return launch_packed_a<4>(NG, sample, grid, a, d, st, tm);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds)
 {
@@ -432,43 +508,43 @@ static int copy_grid(size_t total)
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
 }
 
-hipError_t launch_export_noise(int A, const float* Eint, float* E, int K, int T, int C, int nq,
-                               hipStream_t st)
+hipError_t launch_export_noise(int A, const float* Eint, float* E, int K, int T,
+                               const ELayout& lay, hipStream_t st)
 {
     const int grid = copy_grid((size_t)K * T * A);
     switch (A) {
-        case 1: hipLaunchKernelGGL(k_export_noise<1>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, C, nq); break;
-        case 2: hipLaunchKernelGGL(k_export_noise<2>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, C, nq); break;
-        case 3: hipLaunchKernelGGL(k_export_noise<3>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, C, nq); break;
-        case 4: hipLaunchKernelGGL(k_export_noise<4>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, C, nq); break;
+        case 1: hipLaunchKernelGGL(k_export_noise<1>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, lay); break;
+        case 2: hipLaunchKernelGGL(k_export_noise<2>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, lay); break;
+        case 3: hipLaunchKernelGGL(k_export_noise<3>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, lay); break;
+        case 4: hipLaunchKernelGGL(k_export_noise<4>, dim3(grid), dim3(256), 0, st, Eint, E, K, T, lay); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_import_noise(int A, const float* E, float* Eint, int K, int T, int C, int nq,
-                               hipStream_t st)
+hipError_t launch_import_noise(int A, const float* E, float* Eint, int K, int T,
+                               const ELayout& lay, hipStream_t st)
 {
     const int grid = copy_grid((size_t)K * T * A);
     switch (A) {
-        case 1: hipLaunchKernelGGL(k_import_noise<1>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, C, nq); break;
-        case 2: hipLaunchKernelGGL(k_import_noise<2>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, C, nq); break;
-        case 3: hipLaunchKernelGGL(k_import_noise<3>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, C, nq); break;
-        case 4: hipLaunchKernelGGL(k_import_noise<4>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, C, nq); break;
+        case 1: hipLaunchKernelGGL(k_import_noise<1>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, lay); break;
+        case 2: hipLaunchKernelGGL(k_import_noise<2>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, lay); break;
+        case 3: hipLaunchKernelGGL(k_import_noise<3>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, lay); break;
+        case 4: hipLaunchKernelGGL(k_import_noise<4>, dim3(grid), dim3(256), 0, st, E, Eint, K, T, lay); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_trace_states(int A, const float* Eint, const float* U, const float* x0, float* X,
-                               int K, int T, int C, int nq, float dt, float B0, hipStream_t st)
+                               int K, int T, const ELayout& lay, float dt, float B0, hipStream_t st)
 {
     const int grid = (K + 255) / 256;
     switch (A) {
-        case 1: hipLaunchKernelGGL(k_trace_states<1>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, C, nq, dt, B0); break;
-        case 2: hipLaunchKernelGGL(k_trace_states<2>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, C, nq, dt, B0); break;
-        case 3: hipLaunchKernelGGL(k_trace_states<3>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, C, nq, dt, B0); break;
-        case 4: hipLaunchKernelGGL(k_trace_states<4>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, C, nq, dt, B0); break;
+        case 1: hipLaunchKernelGGL(k_trace_states<1>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
+        case 2: hipLaunchKernelGGL(k_trace_states<2>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
+        case 3: hipLaunchKernelGGL(k_trace_states<3>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
+        case 4: hipLaunchKernelGGL(k_trace_states<4>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -9,6 +9,10 @@
 //                   one float4 = the 4 normals of one Philox block (flat index n = t*A + a,
 //                   block n/4).  Every store and load of it is one full-wave contiguous
 //                   1 KiB dwordx4 access (stores: write-through buffer_store ... sc0 sc1).
+//                   PACKED layout (rollout_packed_impl.hpp): the same container, but a wavefront holds
+//                   TPW whole trajectories laid end to end over its 64*NG group slots (slot
+//                   s = j*NGT + r of trajectory j, group r; lane = s / NG, q = (s % NG)*BPG + b),
+//                   so a trajectory does not have to fill a power-of-two number of lanes.
 //   cost          : [K] floats.
 //   part_m/part_s : [grid] per-block running min and exp-sum (relative to that min).
 //   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
@@ -55,6 +59,9 @@ struct RolloutArgs {
     int c_last;            // chunk holding step T-1; chunks beyond are empty
     int n_last;            // valid steps in chunk c_last (1..L)
     int n_tileblk;         // number of 256-lane tile groups = ceil(K*C/256)
+    int packed;            // != 0: packed layout -- NG = ng groups per lane, NGT groups per
+    int NGT;               //       trajectory, TPW trajectories per wavefront
+    int TPW;
     float dt;
     float B0;              // (float)(dt*dt/2.0)
     float lambda;
@@ -63,6 +70,11 @@ struct RolloutArgs {
     float w[8];
     float sigma[4];
     float inv_s[4];
+    // packed kernel: dynamics on scaled state d_p = sp (p - g_p), d_v = sv (v - g_v) with
+    // sp = sqrt(w_p), sv = sqrt(w_v) (2^-60 where a weight is 0): d_p' = d_p + k1 d_v + k2 a + cg,
+    // d_v' = d_v + k3 a, stage cost d_p'^2 + d_v'^2; computed on the host in double precision
+    float pk_sp[4], pk_sv[4], pk_k1[4], pk_k2[4], pk_k3[4], pk_cg[4], pk_gps[4], pk_gvs[4];
+    int pk_has_cg;         // some velocity goal != 0
     float x0[8];           // host copy of the current state (travels by value in RolloutHot)
     // read only on the riding path (DeferredCombine), kept here so that they cost no kernel
     // argument registers: the tagged finished controls and the device watchdog words
@@ -83,9 +95,11 @@ struct RolloutHot {
     long long k_offset;
     int K, T, TA, NBT, NBTp;
     int logC, ng, nq, L, c_last, n_last, n_tileblk;
+    int NGT, TPW;              // packed layout only
     float x0[8];
 #ifdef MPPI_TRACE      // analysis builds only (tools/trace.sh): per-block region time stamps
     unsigned long long* trace;
+    int trace_tile;            // which tile of a block the packed kernel stamps (MPPI_TRACE_TILE)
 #endif
 };
 #ifdef MPPI_TRACE
@@ -111,9 +125,11 @@ inline RolloutHot make_hot(const RolloutArgs& a)
     h.K = a.K; h.T = a.T; h.TA = a.TA; h.NBT = a.NBT; h.NBTp = a.NBTp;
     h.logC = a.logC; h.ng = a.ng; h.nq = a.nq; h.L = a.L;
     h.c_last = a.c_last; h.n_last = a.n_last; h.n_tileblk = a.n_tileblk;
+    h.NGT = a.NGT; h.TPW = a.TPW;
     for (int i = 0; i < 8; ++i) h.x0[i] = a.x0[i];
 #ifdef MPPI_TRACE
     h.trace = g_mppi_trace_buf;
+    h.trace_tile = getenv("MPPI_TRACE_TILE") ? atoi(getenv("MPPI_TRACE_TILE")) : 0;
 #endif
 #ifdef MPPI_TRACE      // latency probes of the analysis build only: the product never reads them
     if (const char* dbg = getenv("MPPI_DEBUG_SKIP")) {
@@ -213,6 +229,31 @@ constexpr int kSmallCombineNR = 24;   // row loads in flight per lane of the 256
                                       // (16 row groups per block: up to 384 rows per split)
 constexpr int kMaxSmallSplits = 8;    // row splits of the 256-thread combine (one poll batch)
 
+// Optional dispatch timing: when both events are non-null the launch goes through
+// hipExtLaunchKernelGGL, which stamps the events with the dispatch packet's own start / end
+// times (the same timestamps rocprofv3 --kernel-trace reports), not with stream-order markers.
+struct LaunchTiming {
+    hipEvent_t start = nullptr;
+    hipEvent_t stop = nullptr;
+};
+
+// Where sample k's normal (t, a) sits in the noise buffer: the row-aligned layout is described by
+// (C, nq), the packed one by (NG, NGT, TPW) with nq = NG * blocks-per-group.
+struct ELayout {
+    int packed;
+    int C, nq;
+    int NG, NGT, TPW;
+};
+
+// Packed rollout (rollout_packed_impl.hpp): instantiated groups-per-lane values per act_dim
+// (0-terminated), its LDS need and its launcher; grid = rollout blocks, d as for the fused kernel.
+const int* packed_ng_list(int A);
+size_t packed_lds_bytes(int A, int NG, int NBTp, int TPW);
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds);
+hipError_t launch_rollout_packed(int A, int NG, bool sample, int grid, const RolloutArgs& a,
+                                 const DeferredCombine& d, hipStream_t st,
+                                 LaunchTiming tm = LaunchTiming());
+
 // Group geometry by action dimension and the instantiated register-resident chunk lengths
 // (template NG = groups per lane); pick returns the smallest instantiated NG >= ng, 0 if none.
 int rollout_group_steps(int A);
@@ -226,13 +267,6 @@ int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds);   // occupan
 // where the first launch would abort inside the runtime)
 hipError_t probe_code_object(int A);
 
-// Optional dispatch timing: when both events are non-null the launch goes through
-// hipExtLaunchKernelGGL, which stamps the events with the dispatch packet's own start / end
-// times (the same timestamps rocprofv3 --kernel-trace reports), not with stream-order markers.
-struct LaunchTiming {
-    hipEvent_t start = nullptr;
-    hipEvent_t stop = nullptr;
-};
 
 // grid = rollout blocks; d.n_blocks combine-role blocks are launched in front of them
 hipError_t launch_rollout_fused(int A, int NGt, bool sample, int grid, const RolloutArgs& a,
@@ -255,12 +289,12 @@ hipError_t launch_finish_gathered(const CombineArgs& a, const float* gathered, i
                                   hipStream_t st, LaunchTiming tm = LaunchTiming());
 
 // debug / data-movement kernels (off the timed path)
-hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T, int C,
-                               int nq, hipStream_t st);
-hipError_t launch_import_noise(int A, const float* E_ktA, float* Eint, int K, int T, int C,
-                               int nq, hipStream_t st);
+hipError_t launch_export_noise(int A, const float* Eint, float* E_ktA, int K, int T,
+                               const ELayout& lay, hipStream_t st);
+hipError_t launch_import_noise(int A, const float* E_ktA, float* Eint, int K, int T,
+                               const ELayout& lay, hipStream_t st);
 hipError_t launch_trace_states(int A, const float* Eint, const float* U_rollout, const float* x0,
-                               float* X, int K, int T, int C, int nq, float dt, float B0,
+                               float* X, int K, int T, const ELayout& lay, float dt, float B0,
                                hipStream_t st);
 hipError_t launch_weights(const float* cost, const DevState* dev, float lambda, float* wts,
                           int K, hipStream_t st);

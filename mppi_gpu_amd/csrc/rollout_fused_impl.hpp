@@ -29,12 +29,6 @@ struct LaneParams {     // wave-uniform problem constants, deliberately held in 
     float dt, B0, dt2;
 };
 
-__device__ __forceinline__ float to_vgpr(float x)
-{   // opaque move: afterwards the compiler no longer knows the value is wave-uniform
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
 // EXACT: the chunk is exactly NG groups long (ng == NG), so the group checks below fold away.
 // Instantiated where it was measured to pay (kExactGroupsPays): hipcc's schedule of the single
 // straight-line pass is 3.4 % faster for act_dim 2 (NG = 7) and 8 % SLOWER for act_dim 3 (NG = 4).
@@ -188,67 +182,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         }
         if (first) MPPI_STAMP(1);
         if (first) {
-            if constexpr (deferred) {
-                // The combine-role blocks of this very launch are producing this solve's
-                // controls: take them from the tagged words the applying blocks publish (see
-                // DeferredCombine), one value per thread and sweep, polling what is not there
-                // yet (bounded).
-                const unsigned long long t0 = wall_clock64();
-                const unsigned long long limit = g.ride_timeout_ticks;
-                bool timed_out = false;
-                float* uflat = reinterpret_cast<float*>(ulds);
-                float* ucflat = reinterpret_cast<float*>(uclds);
-                const unsigned long long* fin_p = g.fin_tag;
-                const unsigned int tag_want = d.c.tag;
-                constexpr int kBatch = 4;      // words in flight per thread: one round trip, not four
-                for (int base = threadIdx.x; base < NBTp * 4; base += kBatch * kRolloutThreads) {
-                    float unew[kBatch];
-                    bool have[kBatch];
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        unew[j] = 0.0f;
-                        have[j] = base + j * kRolloutThreads >= TA;     // padding: nothing to fetch
-                    }
-                    for (;;) {
-                        unsigned long long w[kBatch];
-#pragma unroll
-                        for (int j = 0; j < kBatch; ++j) {
-                            const int idx = base + j * kRolloutThreads;
-                            const int n = (idx < TA - A) ? idx + A : idx;  // shift; last step repeats
-                            w[j] = have[j] ? 0ull
-                                           : __hip_atomic_load(fin_p + n, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        bool all = true;
-#pragma unroll
-                        for (int j = 0; j < kBatch; ++j) {
-                            if (!have[j] && (unsigned int)(w[j] >> 32) == tag_want) {
-                                unew[j] = __uint_as_float((unsigned int)w[j]);
-                                have[j] = true;
-                            }
-                            all = all && have[j];
-                        }
-                        if (all) break;
-                        if (wall_clock64() - t0 > limit || watchdog_tripped(g.err_dev)) {
-                            timed_out = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        const int idx = base + j * kRolloutThreads;
-                        if (idx < NBTp * 4) {
-                            uflat[idx] = unew[j];
-                            ucflat[idx] = lambda * (unew[j] * g.inv_s[idx % A]);
-                        }
-                    }
-                }
-                if (timed_out) {     // device watchdog word, reported by the next mppi_sync_act
-                    *g.err_dev = 2;
-                    if (g.err_host) *g.err_host = 2;
-                }
-            }
+            if constexpr (deferred) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTp, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
         }
         if (first) MPPI_STAMP(2);

@@ -1,0 +1,700 @@
+// rollout_packed_impl.hpp -- the PACKED fused rollout: whole trajectories laid end to end over the
+// lanes of a wavefront.
+//
+// The row-aligned kernel (rollout_fused_impl.hpp) gives every trajectory a power-of-two number of
+// lanes: at T = 200 a 3-D trajectory is 50 groups of 4 steps, 12.5 lanes of 4 groups, and 16 lanes
+// are spent on it -- 22 % of every pass of every tile (Philox, Box-Muller, dynamics, reductions)
+// is work on lanes past the horizon.  Here a wavefront owns 64*NG consecutive GROUP SLOTS and fills
+// them with TPW = floor(64*NG / NGT) whole trajectories (NGT groups each): slot s = j*NGT + r is
+// group r of the wave's trajectory j and lives in lane s / NG.  A lane therefore holds NG
+// consecutive groups of ONE trajectory, or the last groups of one trajectory followed by the first
+// groups of the next (NGT >= NG: at most one boundary per lane).  T = 200, act_dim 3: 5
+// trajectories in 62.5 lanes (97.7 % of the slots used instead of 78 %); act_dim 2, NG = 8: 5
+// trajectories in 62.5 lanes (instead of 89 %).
+//
+// What changes against the row-aligned kernel:
+//   * the chunk scan is a SEGMENTED scan over the whole wavefront (row_shr inside the DPP rows,
+//     row_bcast:15 / :31 across them) with a "a trajectory starts in my range" flag; a lane with a
+//     boundary hands on the response of its tail only, and starts its own tail from x0;
+//   * a trajectory's cost is a segmented sum of lane partials; the totals go through a per-wave LDS
+//     table so that every lane gets the weight(s) of the trajectories it holds;
+//   * the weighted-noise sums leave the registers through LDS: every lane writes its w*e blocks to
+//     its slot, and after the tile's barrier thread m adds, for Philox block m of the horizon,
+//     the 4 waves x TPW trajectories in fixed order (no DPP reduce-scatter: the trajectories of a
+//     wave no longer sit in aligned lane rows);
+//   * dynamics and cost run on SCALED state variables d_p = sqrt(w_p)(p - g_p),
+//     d_v = sqrt(w_v)(v - g_v), whose stage cost is d_p^2 + d_v^2: 7 VALU instructions per normal
+//     instead of 11 (src/point_mass_gpu.cu:97-107 + src/cost.cu:42-55 are the same arithmetic up
+//     to rounding; the test bar of the fused kernels applies).  Scales and gains come from the host.
+// Requirements (the engine falls back to the row-aligned kernel otherwise): T a whole number of
+// groups, NG <= NGT <= 64*NG, cost weights >= 0.
+#pragma once
+#include "device_common.hpp"
+#include "combine_impl.hpp"
+
+// experiment switches (tools/mkvariant.sh): defaults are the measured best
+#ifndef MPPI_PK_FENCES
+#define MPPI_PK_FENCES 1       // scheduling fences between the groups of passes 1b / 2
+#endif
+#ifndef MPPI_PK_PREFETCH
+#define MPPI_PK_PREFETCH 1     // controls of the next group loaded a group ahead
+#endif
+#if MPPI_PK_FENCES
+#define MPPI_PK_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MPPI_PK_FENCE() do { } while (0)
+#endif
+
+namespace mppi {
+
+template <int A>
+struct PackedLane {     // wave-uniform constants held in VGPRs (see LaneParams in the fused kernel)
+    float sp[A], sv[A];         // state scales
+    float k1[A], k2[A], k3[A];  // d_p' = d_p + k1 d_v + k2 a (+ cg),  d_v' = d_v + k3 a
+    float cg[A];
+    float gps[A], gvs[A];       // scaled goals
+    float sigma[A];
+    float dt, B0, dt2;
+};
+
+template <int A, int NG, bool SAMPLE, bool RIDE>
+__device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredCombine& d)
+{
+    const int bid = RIDE ? (int)blockIdx.x - d.n_blocks : (int)blockIdx.x;
+    const int nblk = RIDE ? (int)gridDim.x - d.n_blocks : (int)gridDim.x;
+    constexpr int SG = Dim<A>::SG;
+    constexpr int BPG = Dim<A>::BPG;
+    constexpr int NQ = NG * BPG;              // Philox blocks per lane
+    constexpr int NE = NQ * 4;                // normals held per lane
+    constexpr int L = NG * SG;                // steps per lane
+
+    const int K = h.K, TA = h.TA, NBT = h.NBT, NGT = h.NGT, TPW = h.TPW;
+    const int n_tileblk = h.n_tileblk;
+    const long long k_offset = h.k_offset;
+    const unsigned long long seed = h.seed;
+    float* const Eint = h.Eint;
+    const RolloutArgs& g = *h.rest;           // cold part of the descriptor (device memory)
+
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBT] U, one float4 per block
+    float4* uclds = ulds + NBT;                                  // [NBT] lambda*inv_s*U
+    float4* buf = uclds + NBT;                                   // [4][64*NQ] weighted noise sums
+    float* misc = reinterpret_cast<float*>(buf + 4 * 64 * NQ);   // [8]
+    float* ctab = misc + 8;                                      // [4][TPW + 2] trajectory costs
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    MPPI_STAMP(0);
+
+    // ---- loads of the nominal controls and the cold constants (complete under the Philox work) --
+    const float lambda = g.lambda, inv_lambda = g.inv_lambda;
+    if constexpr (!RIDE) stage_controls_pair<A>(g, h.U_in, lambda, ulds, uclds, NBT, TA);
+    PackedLane<A> P;
+    float x0p[A], x0v[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        P.sp[i] = to_vgpr(g.pk_sp[i]); P.sv[i] = to_vgpr(g.pk_sv[i]);
+        P.k1[i] = to_vgpr(g.pk_k1[i]); P.k2[i] = to_vgpr(g.pk_k2[i]); P.k3[i] = to_vgpr(g.pk_k3[i]);
+        P.cg[i] = to_vgpr(g.pk_cg[i]);
+        P.gps[i] = to_vgpr(g.pk_gps[i]); P.gvs[i] = to_vgpr(g.pk_gvs[i]);
+        P.sigma[i] = to_vgpr(g.sigma[i]);
+        x0p[i] = to_vgpr(h.x0[i]);
+        x0v[i] = to_vgpr(h.x0[A + i]);
+    }
+    P.dt = to_vgpr(g.dt);
+    P.B0 = to_vgpr(g.B0);
+    P.dt2 = P.dt * P.dt;
+    const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
+    const long long k_cover = g.k_cover;
+    const unsigned int cover_and = g.cover_and;
+    float* const cost_out = g.cost;
+
+    // ---- where this lane's group slots sit (the same for every tile) ---------------------------
+    const int s0 = lane * NG;
+    const int j0 = s0 / NGT;                        // trajectory (of the wave) of the first slot
+    const int r0 = s0 - j0 * NGT;                   // its group
+    const int split = min(NGT - r0, NG);            // groups of trajectory j0 in this lane
+    const bool tail_slot = split < NG;              // trajectory j0 ENDS inside the lane and j0+1
+                                                    // (or the idle rest of the wave) starts
+    const bool starts0 = r0 == 0;                   // the lane starts with a trajectory start
+    const bool ends_head = (NGT - r0) <= NG;        // trajectory j0 ends in this lane
+    const int rbh = r0 * BPG;                       // block of the trajectory = rb? + gi*BPG + b
+    const int rbt = -split * BPG;
+    unsigned int split_mask = 0;                    // bit g: some lane has its boundary after g groups
+#pragma unroll
+    for (int gq = 1; gq < NG; ++gq)
+        if (__ballot(tail_slot && split == gq) != 0ull) split_mask |= 1u << gq;
+    const int flag0 = (tail_slot || starts0) ? 1 : 0;      // a trajectory starts in my range
+    const int n_out = tail_slot ? L - split * SG : L;      // steps of the range handed on
+    const float nh = (float)(split * SG), nt = (float)(L - split * SG);
+    const float tau0 = (float)(r0 * SG) * P.dt;            // time since the start of trajectory j0
+    float dps0[A], dvs0[A];                                 // scaled x0: where a trajectory starts
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        dps0[i] = fmaf(P.sp[i], x0p[i], -P.gps[i]);
+        dvs0[i] = fmaf(P.sv[i], x0v[i], -P.gvs[i]);
+    }
+    const unsigned long long blk_base = h.solve_idx * (unsigned long long)NBT;
+
+    float Mw = INFINITY, Sw = 0.0f;          // this WAVE's running minimum and exp-sum
+    bool first = true;                       // no tile with a valid trajectory folded yet
+    bool staged = false;                     // controls are in LDS (block-uniform)
+    // this lane's slot q of the weighted noise sums is bw[q * 64]: layout [wave][q][lane], so that
+    // every wave-instruction reads / writes one contiguous 1 KiB row (no bank conflicts)
+    float4* const bw = buf + wave * 64 * NQ + lane;
+
+#ifdef MPPI_TRACE
+    int tile_no = 0;
+#define MPPI_PK_STAMP(i) do { if (tile_no == h.trace_tile) MPPI_STAMP(i); } while (0)
+#else
+#define MPPI_PK_STAMP(i) do { } while (0)
+#endif
+    for (int tb = bid; tb < n_tileblk; tb += nblk) {
+        const long long tile = (long long)tb * 4 + wave;           // one wavefront = one tile
+        MPPI_PK_STAMP(11);
+        const long long kh = tile * TPW + j0, kt = kh + 1;         // local sample indices
+        const bool valid_h = j0 < TPW && kh < K;
+        const bool valid_t = tail_slot && j0 + 1 < TPW && kt < K;
+        float* etile = Eint + ((size_t)tile * NQ * 64 + lane) * 4;  // + q*256 floats per block
+        __amdgpu_buffer_rsrc_t e_rsrc;
+        {
+            const unsigned long long tbase =
+                reinterpret_cast<unsigned long long>(Eint + (size_t)tile * NQ * 256);
+            const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)tbase);
+            const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(tbase >> 32));
+            e_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, NQ * 1024, 0x00020000);
+        }
+
+        // ---- pass 1a: draw (or load) the lane's noise and store it (write-through, see the
+        //      fused kernel) -------------------------------------------------------------------
+        float e[NE];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const bool hd = gi < split;
+            if constexpr (SAMPLE) {
+                const unsigned long long kg = (unsigned long long)(k_offset + (hd ? kh : kt));
+                const unsigned long long blkg =
+                    blk_base + (unsigned long long)(long long)((hd ? rbh : rbt) + gi * BPG);
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) {
+                    const int q = gi * BPG + b;
+                    const uint4 r = PhiloxAt::block(blkg + (unsigned long long)b, kg, seed);
+                    float z[4];
+                    box_muller_hw(r.x, r.y, z[0], z[1]);
+                    box_muller_hw(r.z, r.w, z[2], z[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[q * 4 + i] = P.sigma[(q * 4 + i) % A] * z[i];
+                }
+                // (one group at a time: left alone, hipcc interleaves the Philox chains of all
+                //  groups of the lane and runs out of registers; the VALU is saturated by one)
+                __builtin_amdgcn_sched_barrier(0);
+                if (hd ? valid_h : valid_t) {      // idle slots and samples >= K store nothing
+#pragma unroll
+                    for (int b = 0; b < BPG; ++b) {
+                        const int q = gi * BPG + b;
+                        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                        const v4u val = {__float_as_uint(e[q * 4]), __float_as_uint(e[q * 4 + 1]),
+                                         __float_as_uint(e[q * 4 + 2]), __float_as_uint(e[q * 4 + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                               17 /* sc0 | sc1 */);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) {
+                    const int q = gi * BPG + b;
+                    const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);
+                    e[q * 4] = t.x; e[q * 4 + 1] = t.y; e[q * 4 + 2] = t.z; e[q * 4 + 3] = t.w;
+                }
+            }
+        }
+        MPPI_PK_STAMP(1);
+        if (!staged) {
+            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBT, TA);
+            __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
+            staged = true;
+        }
+        MPPI_PK_STAMP(2);
+
+        // ---- pass 1b: zero-state response of the lane's range(s): V = dt*S1,
+        //      P = B0*S1 + dt^2*((n-1)*S1 - S2), S1 = sum a_j, S2 = sum j*a_j, a = u + e.
+        //      A lane with a boundary needs the sums of its head [0, split) and tail separately:
+        //      the running sums are snapshot after group `split` (wave-uniform test first). -----
+        float S1[A], S2[A], S1h[A], S2h[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; S1h[i] = 0.f; S2h[i] = 0.f; }
+        float4 unext[BPG];                      // controls of the NEXT group: loaded a group ahead
+#pragma unroll
+        for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbh + b];       // (group 0 is always head)
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            // (group by group: without the scheduling fences hipcc hoists the LDS loads of all
+            //  groups to the top of the pass and holds them in registers)
+            MPPI_PK_FENCE();
+#if !MPPI_PK_PREFETCH
+            {
+                const int rbc = ((gi < split) ? rbh : rbt) + gi * BPG;
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbc + b];
+            }
+#endif
+            float u[BPG * 4];
+#pragma unroll
+            for (int b = 0; b < BPG; ++b) {
+                u[b * 4 + 0] = unext[b].x; u[b * 4 + 1] = unext[b].y;
+                u[b * 4 + 2] = unext[b].z; u[b * 4 + 3] = unext[b].w;
+            }
+#if MPPI_PK_PREFETCH
+            if (gi + 1 < NG) {
+                const int rbn = ((gi + 1 < split) ? rbh : rbt) + (gi + 1) * BPG;
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbn + b];
+            }
+#endif
+#pragma unroll
+            for (int s = 0; s < SG; ++s) {
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const float a = u[s * A + i] + e[gi * BPG * 4 + s * A + i];
+                    S1[i] += a;
+                    S2[i] = fmaf((float)(gi * SG + s), a, S2[i]);
+                }
+            }
+            if (gi + 1 < NG && (split_mask & (1u << (gi + 1)))) {
+                const bool here = tail_slot && split == gi + 1;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    S1h[i] = here ? S1[i] : S1h[i];
+                    S2h[i] = here ? S2[i] : S2h[i];
+                }
+            }
+        }
+        float Pz[A], Vz[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if (!tail_slot) { S1h[i] = S1[i]; S2h[i] = S2[i]; }
+            const float S1t = S1[i] - S1h[i];
+            const float S2t = (S2[i] - S2h[i]) - nh * S1t;      // steps counted from the boundary
+            const float S1o = tail_slot ? S1t : S1h[i];
+            const float S2o = tail_slot ? S2t : S2h[i];
+            const float no = tail_slot ? nt : nh;
+            Vz[i] = P.dt * S1o;
+            Pz[i] = fmaf(P.dt2, fmaf(no - 1.0f, S1o, -S2o), P.B0 * S1o);
+        }
+
+        // ---- segmented affine scan over the wavefront: (n, P, V) o (n', P', V') =
+        //      (n + n', P + n'*dt*V + P', V + V'); a range that holds a trajectory start (flag)
+        //      absorbs nothing from its left. --------------------------------------------------
+        {
+            int nacc = n_out, flg = flag0;
+            const int cr = lane & 15;
+#define MPPI_PK_COMBINE(COND, GETF, GETI)                                           \
+            {                                                                       \
+                const int nl = GETI(nacc);                                          \
+                const int fl = GETI(flg);                                           \
+                float Pl[A], Vl[A];                                                 \
+                _Pragma("unroll") for (int i = 0; i < A; ++i) {                     \
+                    Pl[i] = GETF(Pz[i]);                                            \
+                    Vl[i] = GETF(Vz[i]);                                            \
+                }                                                                   \
+                if ((COND) && flg == 0) {                                           \
+                    const float tau = (float)nacc * P.dt;                           \
+                    _Pragma("unroll") for (int i = 0; i < A; ++i) {                 \
+                        Pz[i] = fmaf(tau, Vl[i], Pl[i]) + Pz[i];                    \
+                        Vz[i] = Vl[i] + Vz[i];                                      \
+                    }                                                               \
+                    nacc += nl;                                                     \
+                    flg = fl;                                                       \
+                }                                                                   \
+            }
+            MPPI_PK_COMBINE(cr >= 1, dpp<MPPI_ROW_SHR(1)>, dppi<MPPI_ROW_SHR(1)>)
+            MPPI_PK_COMBINE(cr >= 2, dpp<MPPI_ROW_SHR(2)>, dppi<MPPI_ROW_SHR(2)>)
+            MPPI_PK_COMBINE(cr >= 4, dpp<MPPI_ROW_SHR(4)>, dppi<MPPI_ROW_SHR(4)>)
+            MPPI_PK_COMBINE(cr >= 8, dpp<MPPI_ROW_SHR(8)>, dppi<MPPI_ROW_SHR(8)>)
+            MPPI_PK_COMBINE((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
+            MPPI_PK_COMBINE((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
+#undef MPPI_PK_COMBINE
+        }
+        MPPI_PK_STAMP(3);
+        // start state of the lane's head, scaled: x0 moved freely for the time since the start of
+        // its trajectory plus what the lanes before it contributed
+        float dps[A], dvs[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            float Pex = dpp<kWaveShr1>(Pz[i]);
+            float Vex = dpp<kWaveShr1>(Vz[i]);
+            if (starts0) { Pex = 0.f; Vex = 0.f; }
+            const float p = fmaf(tau0, x0v[i], x0p[i]) + Pex;
+            const float v = x0v[i] + Vex;
+            dps[i] = fmaf(P.sp[i], p, -P.gps[i]);
+            dvs[i] = fmaf(P.sv[i], v, -P.gvs[i]);
+        }
+
+        // ---- pass 2: dynamics + stage cost on the scaled state (src/point_mass_gpu.cu:97-107,
+        //      src/cost.cu:42-55).  One cost accumulator per axis; where a trajectory ends inside
+        //      a lane, its sum (+ Cost::final_cost, src/cost.cu:57-64) is set aside and the lane
+        //      goes on from x0 with the next trajectory. ----------------------------------------
+        float racc[A];
+        float cH = 0.0f;
+#pragma unroll
+        for (int i = 0; i < A; ++i) racc[i] = 0.0f;
+        float4 cnext[BPG];
+#pragma unroll
+        for (int b = 0; b < BPG; ++b) { unext[b] = ulds[rbh + b]; cnext[b] = uclds[rbh + b]; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            MPPI_PK_FENCE();
+#if !MPPI_PK_PREFETCH
+            {
+                const int rbc = ((gi < split) ? rbh : rbt) + gi * BPG;
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) { unext[b] = ulds[rbc + b]; cnext[b] = uclds[rbc + b]; }
+            }
+#endif
+            float u[BPG * 4], uc[BPG * 4];
+#pragma unroll
+            for (int b = 0; b < BPG; ++b) {
+                u[b * 4 + 0] = unext[b].x; u[b * 4 + 1] = unext[b].y;
+                u[b * 4 + 2] = unext[b].z; u[b * 4 + 3] = unext[b].w;
+                uc[b * 4 + 0] = cnext[b].x; uc[b * 4 + 1] = cnext[b].y;
+                uc[b * 4 + 2] = cnext[b].z; uc[b * 4 + 3] = cnext[b].w;
+            }
+#if MPPI_PK_PREFETCH
+            if (gi + 1 < NG) {
+                const int rbn = ((gi + 1 < split) ? rbh : rbt) + (gi + 1) * BPG;
+#pragma unroll
+                for (int b = 0; b < BPG; ++b) { unext[b] = ulds[rbn + b]; cnext[b] = uclds[rbn + b]; }
+            }
+#endif
+#pragma unroll
+            for (int s = 0; s < SG; ++s) {
+                const float* es = &e[gi * BPG * 4 + s * A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    const float a = u[s * A + i] + es[i];
+                    float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
+                    if (has_cg) pn += P.cg[i];
+                    dvs[i] = fmaf(P.k3[i], a, dvs[i]);
+                    dps[i] = pn;
+                    racc[i] = fmaf(uc[s * A + i], es[i], racc[i]);
+                    racc[i] = fmaf(pn, pn, racc[i]);
+                    racc[i] = fmaf(dvs[i], dvs[i], racc[i]);
+                }
+            }
+            if (gi + 1 < NG && (split_mask & (1u << (gi + 1)))) {
+                const bool here = tail_slot && split == gi + 1;
+                float tot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < A; ++i)
+                    tot += fmaf(dps[i], dps[i], fmaf(dvs[i], dvs[i], racc[i]));
+                cH = here ? tot : cH;
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    racc[i] = here ? 0.0f : racc[i];
+                    dps[i] = here ? dps0[i] : dps[i];
+                    dvs[i] = here ? dvs0[i] : dvs[i];
+                }
+            }
+        }
+        float c_last = 0.0f;
+        {
+            const bool term = !tail_slot && ends_head;    // the trajectory ends with the lane
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float fc = fmaf(dps[i], dps[i], dvs[i] * dvs[i]);
+                c_last += racc[i] + (term ? fc : 0.0f);
+            }
+        }
+        const float cA = tail_slot ? cH : c_last;         // my part of trajectory j0
+        MPPI_PK_STAMP(4);
+
+        // ---- trajectory costs: segmented sum of the lane parts over the wavefront -------------
+        float ctA, ctB;
+        {
+            float cz = c_last;                            // the range handed on (tail, or all)
+            int flg = flag0;
+            const int cr = lane & 15;
+#define MPPI_PK_CSUM(COND, GETF, GETI)                                              \
+            {                                                                       \
+                const float cl = GETF(cz);                                          \
+                const int fl = GETI(flg);                                           \
+                if ((COND) && flg == 0) { cz = cl + cz; flg = fl; }                 \
+            }
+            MPPI_PK_CSUM(cr >= 1, dpp<MPPI_ROW_SHR(1)>, dppi<MPPI_ROW_SHR(1)>)
+            MPPI_PK_CSUM(cr >= 2, dpp<MPPI_ROW_SHR(2)>, dppi<MPPI_ROW_SHR(2)>)
+            MPPI_PK_CSUM(cr >= 4, dpp<MPPI_ROW_SHR(4)>, dppi<MPPI_ROW_SHR(4)>)
+            MPPI_PK_CSUM(cr >= 8, dpp<MPPI_ROW_SHR(8)>, dppi<MPPI_ROW_SHR(8)>)
+            MPPI_PK_CSUM((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
+            MPPI_PK_CSUM((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
+#undef MPPI_PK_CSUM
+            float cex = dpp<kWaveShr1>(cz);               // what the lanes before me hold of j0
+            if (starts0) cex = 0.0f;
+            const float tot_h = cex + cA;                 // complete where trajectory j0 ends
+            float* ct = ctab + wave * (TPW + 2);
+            if (ends_head && j0 < TPW) ct[j0] = tot_h;
+            if (ends_head && valid_h) cost_out[kh] = tot_h;
+            __builtin_amdgcn_wave_barrier();              // (same wave: LDS operations stay in order)
+            ctA = ct[j0];
+            ctB = ct[j0 + 1];
+        }
+
+        // ---- wave tail: every WAVE keeps its own running (min, exp-sum, weighted noise sums):
+        //      no block barrier in the tile loop.  The weighted noise of a lane is ACCUMULATED in
+        //      the lane's own LDS slot, rescaled when the wave's running minimum drops; slots of
+        //      different lanes / waves meet once, when the block has walked all its tiles. ------
+        const float m_w = wave_min((ends_head && valid_h) ? ctA : INFINITY);
+        if (m_w < INFINITY) {                            // (wave-uniform) a tile past K adds nothing
+            const float Mn = fminf(Mw, m_w);
+            const float alpha = first ? 0.0f : expf(-inv_lambda * (Mw - Mn));   // 1 if Mn == Mw
+            const float wA = valid_h ? expf(-inv_lambda * (ctA - Mn)) : 0.0f;
+            const float wB = valid_t ? expf(-inv_lambda * (ctB - Mn)) : 0.0f;
+            const float sw = wave_sum(ends_head ? wA : 0.0f);
+            Sw = first ? sw : fmaf(alpha, Sw, sw);
+            Mw = Mn;
+            MPPI_PK_STAMP(5);
+            const unsigned long long kgh = (unsigned long long)(k_offset + kh);
+            const float wAn =
+                ((long long)kgh < k_cover && ((unsigned int)kgh & cover_and) == 0u) ? wA : 0.0f;
+            const float wBn =
+                ((long long)(kgh + 1) < k_cover && ((unsigned int)(kgh + 1) & cover_and) == 0u) ? wB : 0.0f;
+            if (first) {                                 // first tile of the wave: plain write
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const float wg = (gi < split) ? wAn : wBn;
+#pragma unroll
+                    for (int b = 0; b < BPG; ++b) {
+                        const int q = gi * BPG + b;
+                        bw[q * 64] = make_float4(wg * e[q * 4], wg * e[q * 4 + 1], wg * e[q * 4 + 2],
+                                                 wg * e[q * 4 + 3]);
+                    }
+                }
+            } else if (alpha == 1.0f) {                  // running minimum unchanged: accumulate
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const float wg = (gi < split) ? wAn : wBn;
+#pragma unroll
+                    for (int b = 0; b < BPG; ++b) {
+                        const int q = gi * BPG + b;
+                        const float4 o = bw[q * 64];
+                        bw[q * 64] = make_float4(fmaf(wg, e[q * 4], o.x), fmaf(wg, e[q * 4 + 1], o.y),
+                                                 fmaf(wg, e[q * 4 + 2], o.z), fmaf(wg, e[q * 4 + 3], o.w));
+                    }
+                }
+            } else {                                     // a new minimum: rescale what is there
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    const float wg = (gi < split) ? wAn : wBn;
+#pragma unroll
+                    for (int b = 0; b < BPG; ++b) {
+                        const int q = gi * BPG + b;
+                        const float4 o = bw[q * 64];
+                        bw[q * 64] = make_float4(fmaf(wg, e[q * 4], alpha * o.x), fmaf(wg, e[q * 4 + 1], alpha * o.y),
+                                                 fmaf(wg, e[q * 4 + 2], alpha * o.z), fmaf(wg, e[q * 4 + 3], alpha * o.w));
+                    }
+                }
+            }
+            MPPI_PK_STAMP(6); MPPI_PK_STAMP(7); MPPI_PK_STAMP(8);
+            first = false;
+        }
+#ifdef MPPI_TRACE
+        ++tile_no;
+#endif
+    }
+#undef MPPI_PK_STAMP
+    MPPI_STAMP(9);
+
+    // ---- the block's partial: the four waves' running sums meet here, once ------------------------
+    //      M = min M_w, r_w = exp(-(M_w - M)/lambda), S = sum r_w S_w, and thread m adds Philox block m
+    //      of the horizon over the 4 waves x TPW trajectories in fixed order (a wave that saw no
+    //      valid trajectory has r_w = 0 and is skipped: its slots were never written)
+    if (lane == 0) {
+        misc[wave] = Mw;
+        misc[4 + wave] = Sw;
+    }
+    __syncthreads();
+    {
+        const float M = fminf(fminf(misc[0], misc[1]), fminf(misc[2], misc[3]));
+        float rw[4];
+        float S = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            rw[w] = (misc[w] < INFINITY) ? expf(-inv_lambda * (misc[w] - M)) : 0.0f;
+            S = fmaf(rw[w], misc[4 + w], S);
+        }
+        // work item (m, w): Philox block m of the horizon, wave w: thread t takes w = t % 4 and
+        // m = t / 4 (+ 64 per sweep), adds that wave's TPW trajectories (all loads in flight), and
+        // the four waves of a column meet inside the quad (DPP, fixed order)
+        float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * TA);
+        const int wq = threadIdx.x & 3;
+        const float rq = (wq == 0) ? rw[0] : (wq == 1) ? rw[1] : (wq == 2) ? rw[2] : rw[3];
+        const float4* srcw = buf + wq * 64 * NQ;
+        for (int m0 = 0; m0 < NBT; m0 += kRolloutThreads / 4) {
+            const int m = m0 + (threadIdx.x >> 2);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < NBT && rq != 0.0f) {
+                const int r = m / BPG, b = m - r * BPG;      // group and block of the trajectory
+                int jj = 0;
+                for (; jj + 5 <= TPW; jj += 5) {
+                    float4 v[5];
+#pragma unroll
+                    for (int x = 0; x < 5; ++x) {
+                        const int sl = (jj + x) * NGT + r;    // group slot of the wavefront
+                        const int ln = sl / NG;
+                        v[x] = srcw[((sl - ln * NG) * BPG + b) * 64 + ln];
+                    }
+#pragma unroll
+                    for (int x = 0; x < 5; ++x) {
+                        acc.x += v[x].x; acc.y += v[x].y; acc.z += v[x].z; acc.w += v[x].w;
+                    }
+                }
+                for (; jj < TPW; ++jj) {
+                    const int sl = jj * NGT + r;
+                    const int ln = sl / NG;
+                    const float4 v4 = srcw[((sl - ln * NG) * BPG + b) * 64 + ln];
+                    acc.x += v4.x; acc.y += v4.y; acc.z += v4.z; acc.w += v4.w;
+                }
+                acc.x *= rq; acc.y *= rq; acc.z *= rq; acc.w *= rq;
+            }
+            // (w0 + w1) + (w2 + w3), every lane of the quad ends with the same bits
+            acc.x += dpp<kQuadXor1>(acc.x); acc.y += dpp<kQuadXor1>(acc.y);
+            acc.z += dpp<kQuadXor1>(acc.z); acc.w += dpp<kQuadXor1>(acc.w);
+            acc.x += dpp<kQuadXor2>(acc.x); acc.y += dpp<kQuadXor2>(acc.y);
+            acc.z += dpp<kQuadXor2>(acc.z); acc.w += dpp<kQuadXor2>(acc.w);
+            if (m < NBT && wq == 0) Nout[m] = acc;
+        }
+        if (threadIdx.x == 0) {
+            g.part_m[bid] = M;
+            g.part_s[bid] = S;
+        }
+    }
+    MPPI_STAMP(10);
+}
+
+// The noise of a lane stays in registers across all passes: two waves per SIMD where that is more
+// than 32 normals (<= 256 VGPRs), else three (<= 168).
+template <int A, int NG>
+constexpr int packed_min_waves()
+{
+    return NG * Dim<A>::BPG * 4 <= 32 ? 3 : 2;
+}
+
+template <int A, int NG, bool SAMPLE>
+__global__ void __launch_bounds__(kRolloutThreads, (packed_min_waves<A, NG>()))
+k_rollout_packed(const RolloutHot h)
+{
+    packed_body<A, NG, SAMPLE, false>(h, DeferredCombine());
+}
+
+// the same with the previous solve's combine riding at the front of the grid (see k_rollout_ride)
+template <int A, int NG, bool SAMPLE>
+__global__ void __launch_bounds__(kRolloutThreads, (packed_min_waves<A, NG>()))
+k_rollout_packed_ride(const RolloutHot h, const DeferredCombine d)
+{
+    if ((int)blockIdx.x < d.n_blocks) {
+        __builtin_amdgcn_s_setprio(3);
+        MPPI_STAMP(0);
+        extern __shared__ __align__(16) unsigned char smem_raw[];
+        combine_body<kRolloutThreads, kSmallCombineNR>(
+            d.c, (int)blockIdx.x,
+            carve_combine_smem<kRolloutThreads>(reinterpret_cast<float*>(smem_raw)));
+        MPPI_STAMP(10);
+        return;
+    }
+    packed_body<A, NG, SAMPLE, true>(h, d);
+}
+
+template <int A, int NG>
+size_t packed_lds_bytes_t(int NBT, int TPW)
+{
+    return (size_t)NBT * 2 * 16 + (size_t)4 * 64 * NG * Dim<A>::BPG * 16
+           + (size_t)(8 + 4 * (TPW + 2)) * sizeof(float);
+}
+
+template <int A, int NG>
+hipError_t launch_packed_t(bool sample, int grid, const RolloutArgs& a, const DeferredCombine& d,
+                           hipStream_t st, LaunchTiming tm)
+{
+    size_t lds = packed_lds_bytes_t<A, NG>(a.NBT, a.TPW);
+    if (d.n_blocks > 0 && lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
+    const RolloutHot h = make_hot(a);
+    const dim3 g(grid + d.n_blocks), b(kRolloutThreads);
+    if (d.n_blocks > 0) {
+        if (sample) MPPI_LAUNCH((k_rollout_packed_ride<A, NG, true>), g, b, lds, st, tm, h, d);
+        else MPPI_LAUNCH((k_rollout_packed_ride<A, NG, false>), g, b, lds, st, tm, h, d);
+    } else {
+        if (sample) MPPI_LAUNCH((k_rollout_packed<A, NG, true>), g, b, lds, st, tm, h);
+        else MPPI_LAUNCH((k_rollout_packed<A, NG, false>), g, b, lds, st, tm, h);
+    }
+    return hipGetLastError();
+}
+
+template <int A, int NG>
+int packed_blocks_per_cu_t(bool sample, size_t lds)
+{
+    int n = 0;
+    hipError_t rc = sample
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, true>,
+                                                       kRolloutThreads, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, false>,
+                                                       kRolloutThreads, lds);
+    return rc == hipSuccess ? n : 0;
+}
+
+// instantiated groups-per-lane values: chosen so that T = 200 packs well (see packed_ng_list)
+template <int A> struct PackedNG;
+template <> struct PackedNG<1> { static constexpr int list[] = {4, 0}; };
+template <> struct PackedNG<2> { static constexpr int list[] = {5, 8, 0}; };
+template <> struct PackedNG<3> { static constexpr int list[] = {4, 0}; };
+template <> struct PackedNG<4> { static constexpr int list[] = {10, 0}; };
+
+template <int A>
+hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
+                           const DeferredCombine& d, hipStream_t st, LaunchTiming tm)
+{
+    if constexpr (A == 1) {
+        if (NG == 4) return launch_packed_t<1, 4>(sample, grid, a, d, st, tm);
+    } else if constexpr (A == 2) {
+        if (NG == 5) return launch_packed_t<2, 5>(sample, grid, a, d, st, tm);
+        if (NG == 8) return launch_packed_t<2, 8>(sample, grid, a, d, st, tm);
+    } else if constexpr (A == 3) {
+        if (NG == 4) return launch_packed_t<3, 4>(sample, grid, a, d, st, tm);
+    } else {
+        if (NG == 10) return launch_packed_t<4, 10>(sample, grid, a, d, st, tm);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int A>
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds)
+{
+    if constexpr (A == 1) {
+        if (NG == 4) return packed_blocks_per_cu_t<1, 4>(sample, lds);
+    } else if constexpr (A == 2) {
+        if (NG == 5) return packed_blocks_per_cu_t<2, 5>(sample, lds);
+        if (NG == 8) return packed_blocks_per_cu_t<2, 8>(sample, lds);
+    } else if constexpr (A == 3) {
+        if (NG == 4) return packed_blocks_per_cu_t<3, 4>(sample, lds);
+    } else {
+        if (NG == 10) return packed_blocks_per_cu_t<4, 10>(sample, lds);
+    }
+    return 0;
+}
+
+template <int A>
+size_t packed_lds_bytes_a(int NG, int NBT, int TPW)
+{
+    if constexpr (A == 1) {
+        if (NG == 4) return packed_lds_bytes_t<1, 4>(NBT, TPW);
+    } else if constexpr (A == 2) {
+        if (NG == 5) return packed_lds_bytes_t<2, 5>(NBT, TPW);
+        if (NG == 8) return packed_lds_bytes_t<2, 8>(NBT, TPW);
+    } else if constexpr (A == 3) {
+        if (NG == 4) return packed_lds_bytes_t<3, 4>(NBT, TPW);
+    } else {
+        if (NG == 10) return packed_lds_bytes_t<4, 10>(NBT, TPW);
+    }
+    return 0;
+}
+
+}  // namespace mppi

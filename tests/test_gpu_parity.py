@@ -157,6 +157,89 @@ def test_fused_kernel_matches_oracle(gpu, A, K, T, chunks):
     _check_solve(act, inf, ref, cost_exact=False, tag=f"fused A{A} K{K} T{T} {geo}")
 
 
+PACKED_CASES = [
+    # A, K, T, groups per lane (0 = the engine's choice), max_blocks
+    (3, 1024, 200, 0, 0),      # config 3 horizon: 5 trajectories per wavefront
+    (3, 1000, 200, 4, 3),      # ... on a persistent grid of 3 blocks (rescale path)
+    (2, 1000, 200, 8, 0),      # config 2 horizon, 8 groups per lane: 5 trajectories per wavefront
+    (2, 1000, 200, 5, 0),      # ... 5 groups per lane: 3 trajectories per wavefront
+    (2, 3, 12, 5, 0),          # mppi-config-test.yaml shape: 6 groups per trajectory
+    (2, 257, 50, 0, 0),
+    (3, 300, 52, 4, 0),        # 13 groups per trajectory: 19 trajectories per wavefront
+    (1, 700, 204, 4, 0),
+    (1, 64, 16, 4, 0),         # one lane per trajectory
+    (4, 130, 37, 10, 0),
+    (4, 50, 400, 10, 1),       # 400 groups per trajectory: one trajectory per wavefront
+    (3, 7, 512, 4, 0),         # 128 groups per trajectory: two per wavefront
+]
+
+
+@pytest.mark.parametrize("A,K,T,ngl,max_blocks", PACKED_CASES)
+def test_packed_kernel_matches_oracle(gpu, A, K, T, ngl, max_blocks):
+    """The packed rollout (whole trajectories end to end over the lanes, scaled-state dynamics)
+    against the oracle on injected noise, in every shape class: boundaries in mid-lane and at lane
+    ends, idle slots at the end of a wavefront, several tiles per block."""
+    c = ol.make_case(A, K, T, seed=400 + A * 7 + T)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    with _model(gpu, A, K, T, c, max_blocks=max_blocks) as m:
+        if ngl:
+            m.set_packing(ngl)
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf()
+        geo = m.geometry()
+    assert geo["packed"] and (ngl == 0 or geo["groups_per_lane"] == ngl), geo
+    assert np.array_equal(inf["e"], c["E"]), "injected noise must round-trip through the packed layout"
+    _check_solve(act, inf, ref, cost_exact=False, tag=f"packed A{A} K{K} T{T} {geo}")
+    cost, X = ol.rollout(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], want_X=True)
+    assert np.array_equal(inf["x"], X), "state trace reads the packed layout"
+
+
+def test_packed_kernel_general_goal_and_zero_weights(gpu):
+    """Velocity goals != 0 (the scaled position drifts by a constant per step), zero weights on
+    single axes (scale 2^-60 instead of sqrt(w)), lambda and inv_s != 1."""
+    A, K, T = 3, 900, 48
+    c = ol.make_case(A, K, T, seed=71, u_scale=0.2)
+    c["goal"] = np.array([1, .5, .75, .3, -.2, .1], np.float32)
+    c["w"] = np.array([2, 0, 1, 5, 3, 0], np.float32)
+    lam, inv_s = 1.7, np.array([2.0, 0.5, 1.25], np.float32)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=lam, inv_s=inv_s)
+    with _model(gpu, A, K, T, c) as m:
+        m.set_packing(4)
+        m.set_params(lam, inv_s=inv_s)
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf(x=False, e=False)
+        assert m.geometry()["packed"]
+    _check_solve(act, inf, ref, cost_exact=False, tag="packed goal/zero-w", lam=lam)
+    # negative weights are not a cost the scaled form can carry: the row-aligned kernel takes over
+    c["w"] = np.array([2, -1, 1, 5, 3, 0], np.float32)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])
+    with _model(gpu, A, K, T, c) as m:
+        m.set_noise(c["E"])
+        act = m.get_act()
+        inf = m.get_inf(x=False, e=False)
+        assert not m.geometry()["packed"]
+    _check_solve(act, inf, ref, cost_exact=False, tag="negative w falls back")
+
+
+def test_packing_is_refused_where_it_does_not_apply(gpu):
+    from mppi_gpu_amd import MppiError
+    c = ol.make_case(3, 100, 50, seed=3)                 # T = 50 is not a multiple of 4 steps
+    with _model(gpu, 3, 100, 50, c) as m:
+        assert not m.geometry()["packed"]
+        with pytest.raises(MppiError):
+            m.set_packing(4)
+        m.set_packing(-1)
+    c = ol.make_case(3, 100, 200, seed=3)
+    with _model(gpu, 3, 100, 200, c) as m:
+        assert m.geometry()["packed"]
+        with pytest.raises(MppiError):
+            m.set_packing(7)                             # not an instantiated size
+        m.set_packing(-1)
+        assert not m.geometry()["packed"]
+
+
 def test_states_trace_matches_oracle(gpu):
     A, K, T = 3, 200, 50
     c = ol.make_case(A, K, T, seed=5)

@@ -15,6 +15,7 @@ from mppi_gpu_amd import PointMassModel, _capi
 
 A, K, T = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (2, 10000, 200)))
 chunks = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+packing = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 lib = _capi.load()
 lib.mppi_debug_trace.restype = C.c_int
 lib.mppi_debug_trace.argtypes = [C.c_void_p, C.c_int]
@@ -22,6 +23,8 @@ assert lib.mppi_debug_trace(None, 0) == 0
 c = ol.make_case(A, 1, T, seed=0, u_scale=0.0)
 m = PointMassModel(K, T, float(c["dt"]), 2 * A, A)
 m.set_tuning(chunks=chunks, strict=0, max_blocks=0)
+if packing:
+    m.set_packing(packing)
 m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
 for _ in range(50):
     m.solve_async()
@@ -56,6 +59,9 @@ if nb:
     print("rollout blocks start p50/max", np.median(buf[:, 0].astype(np.int64) - t00),
           (buf[:, 0].astype(np.int64) - t00).max(), " end max", (buf[:, 10].astype(np.int64) - t00).max())
 t = buf.astype(np.int64)
+if int(os.environ.get("MPPI_TRACE_TILE", "0")) > 0 and geo["packed"]:
+    t = t[t[:, 11] > 0]           # packed kernel, a later tile: ticks since THAT tile's start
+    t[:, 0] = t[:, 11]
 d = t[:, :11] - t[:, :1]          # per block: ticks since its own entry (counters differ per XCD)
 names = ["entry", "pass1a done", "barrier 1", "1b+scan", "pass2", "min+exp", "nreduce", "barrier 2",
          "fold", "all tiles", "exit"]
