@@ -242,6 +242,11 @@ int ensure_geometry(mppi_engine_t* e)
                         e->user_packing, e->T, e->A, e->SG);
         const double util_row = (double)NGT / ((double)C * ng);
         packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
+        // Packing buys throughput: fewer, fuller tiles.  A launch so short that no block would walk
+        // a second tile (K = 1e4, 2-D: 500 tile groups) is a latency problem instead, and there
+        // the row-aligned kernel's shorter tail wins (measured 13.2 against 14.7 us at C2).
+        if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
+            packed = false;
         if (packed && e->user_packing <= 0 &&
             mppi::packed_lds_bytes(e->A, pk_NG, e->NBT, TPW) > 64 * 1024)
             packed = false;          // horizon too long for the LDS slots: row-aligned kernel

@@ -159,12 +159,13 @@ def test_fused_kernel_matches_oracle(gpu, A, K, T, chunks):
 
 PACKED_CASES = [
     # A, K, T, groups per lane (0 = the engine's choice), max_blocks
-    (3, 1024, 200, 0, 0),      # config 3 horizon: 5 trajectories per wavefront
+    (3, 1024, 200, 4, 0),      # config 3 horizon: 5 trajectories per wavefront
+    (3, 10300, 200, 0, 0),     # the engine's own choice for a launch of many tiles
     (3, 1000, 200, 4, 3),      # ... on a persistent grid of 3 blocks (rescale path)
     (2, 1000, 200, 8, 0),      # config 2 horizon, 8 groups per lane: 5 trajectories per wavefront
     (2, 1000, 200, 5, 0),      # ... 5 groups per lane: 3 trajectories per wavefront
     (2, 3, 12, 5, 0),          # mppi-config-test.yaml shape: 6 groups per trajectory
-    (2, 257, 50, 0, 0),
+    (2, 257, 50, 5, 0),
     (3, 300, 52, 4, 0),        # 13 groups per trajectory: 19 trajectories per wavefront
     (1, 700, 204, 4, 0),
     (1, 64, 16, 4, 0),         # one lane per trajectory
@@ -233,11 +234,17 @@ def test_packing_is_refused_where_it_does_not_apply(gpu):
         m.set_packing(-1)
     c = ol.make_case(3, 100, 200, seed=3)
     with _model(gpu, 3, 100, 200, c) as m:
+        assert not m.geometry()["packed"]                # a short launch: latency, not throughput
+        m.set_packing(4)
         assert m.geometry()["packed"]
         with pytest.raises(MppiError):
             m.set_packing(7)                             # not an instantiated size
+        assert m.geometry()["packed"]                    # (the refused call changed nothing)
         m.set_packing(-1)
         assert not m.geometry()["packed"]
+    c = ol.make_case(3, 1, 200, seed=3)
+    with _model(gpu, 3, 12000, 200, c) as m:             # many tiles per block: packed by itself
+        assert m.geometry()["packed"] and m.geometry()["trajectories_per_wave"] == 5
 
 
 def test_states_trace_matches_oracle(gpu):
