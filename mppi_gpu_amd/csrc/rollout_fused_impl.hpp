@@ -5,6 +5,10 @@
 #include "device_common.hpp"
 #include "combine_impl.hpp"
 
+#ifndef MPPI_FUSED_PRIO
+#define MPPI_FUSED_PRIO 2      // s_setprio of the passes after the Philox pass (which runs at 0)
+#endif
+
 namespace mppi {
 
 // ------------------------------------------------------------------------------------------
@@ -139,6 +143,11 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         // resource); an opaque scalar copy per pass keeps them s_cmp + s_cbranch.
         int ngs = EXACT ? NG : ng;
         if constexpr (!EXACT) asm volatile("" : "+s"(ngs));
+        // instruction priority by phase (see rollout_packed_impl.hpp): the Philox pass yields to
+        // the dependent chains of the passes after it
+#if MPPI_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float e[NE];
         // (groups gi >= ng of a template larger than the chunk are never read: every use below
         //  sits under the same wave-uniform `gi < ng`, so e[] needs no initialisation)
@@ -181,6 +190,9 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
             }
         }
         if (first) MPPI_STAMP(1);
+#if MPPI_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(MPPI_FUSED_PRIO);
+#endif
         if (first) {
             if constexpr (deferred) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTp, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on

@@ -39,6 +39,9 @@
 #ifndef MPPI_PK_PREFETCH
 #define MPPI_PK_PREFETCH 1     // controls of the next group loaded a group ahead
 #endif
+#ifndef MPPI_PK_PRIO
+#define MPPI_PK_PRIO 2         // s_setprio of the latency-bound passes (the Philox pass runs at 0)
+#endif
 #if MPPI_PK_FENCES
 #define MPPI_PK_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -52,7 +55,6 @@ struct PackedLane {     // wave-uniform constants held in VGPRs (see LaneParams 
     float sp[A], sv[A];         // state scales
     float k1[A], k2[A], k3[A];  // d_p' = d_p + k1 d_v + k2 a (+ cg),  d_v' = d_v + k3 a
     float cg[A];
-    float gps[A], gvs[A];       // scaled goals
     float sigma[A];
     float dt, B0, dt2;
 };
@@ -90,16 +92,12 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const float lambda = g.lambda, inv_lambda = g.inv_lambda;
     if constexpr (!RIDE) stage_controls_pair<A>(g, h.U_in, lambda, ulds, uclds, NBT, TA);
     PackedLane<A> P;
-    float x0p[A], x0v[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         P.sp[i] = to_vgpr(g.pk_sp[i]); P.sv[i] = to_vgpr(g.pk_sv[i]);
         P.k1[i] = to_vgpr(g.pk_k1[i]); P.k2[i] = to_vgpr(g.pk_k2[i]); P.k3[i] = to_vgpr(g.pk_k3[i]);
         P.cg[i] = to_vgpr(g.pk_cg[i]);
-        P.gps[i] = to_vgpr(g.pk_gps[i]); P.gvs[i] = to_vgpr(g.pk_gvs[i]);
         P.sigma[i] = to_vgpr(g.sigma[i]);
-        x0p[i] = to_vgpr(h.x0[i]);
-        x0v[i] = to_vgpr(h.x0[A + i]);
     }
     P.dt = to_vgpr(g.dt);
     P.B0 = to_vgpr(g.B0);
@@ -127,12 +125,18 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const int flag0 = (tail_slot || starts0) ? 1 : 0;      // a trajectory starts in my range
     const int n_out = tail_slot ? L - split * SG : L;      // steps of the range handed on
     const float nh = (float)(split * SG), nt = (float)(L - split * SG);
-    const float tau0 = (float)(r0 * SG) * P.dt;            // time since the start of trajectory j0
-    float dps0[A], dvs0[A];                                 // scaled x0: where a trajectory starts
+    // scaled x0 (where a trajectory starts) and x0 moved freely to the lane's first step: the start
+    // state of the lane's head is dps1 + sp * (what the lanes before it contributed), likewise dvs
+    float dps0[A], dvs0[A], dps1[A];
+    {
+        const float tau0 = (float)(r0 * SG) * P.dt;        // time since the start of trajectory j0
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-        dps0[i] = fmaf(P.sp[i], x0p[i], -P.gps[i]);
-        dvs0[i] = fmaf(P.sv[i], x0v[i], -P.gvs[i]);
+        for (int i = 0; i < A; ++i) {
+            const float x0p = h.x0[i], x0v = h.x0[A + i];
+            dps0[i] = fmaf(P.sp[i], x0p, -g.pk_gps[i]);
+            dvs0[i] = fmaf(P.sv[i], x0v, -g.pk_gvs[i]);
+            dps1[i] = fmaf(P.sp[i], tau0 * x0v, dps0[i]);
+        }
     }
     const unsigned long long blk_base = h.solve_idx * (unsigned long long)NBT;
 
@@ -168,6 +172,13 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 
         // ---- pass 1a: draw (or load) the lane's noise and store it (write-through, see the
         //      fused kernel) -------------------------------------------------------------------
+        // Instruction priority by phase: the Philox pass can issue every cycle it is offered, the
+        // passes after it are chains of dependent instructions.  Left at equal priority the OLDER
+        // of the two waves of a SIMD wins every arbitration: the first block of a CU ran its tiles
+        // in 66 us, the second in 90 (the kernel's time).  Low priority here, high below.
+#if MPPI_PK_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float e[NE];
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -210,6 +221,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             }
         }
         MPPI_PK_STAMP(1);
+#if MPPI_PK_PRIO
+        __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
+#endif
         if (!staged) {
             if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBT, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
@@ -325,10 +339,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             float Pex = dpp<kWaveShr1>(Pz[i]);
             float Vex = dpp<kWaveShr1>(Vz[i]);
             if (starts0) { Pex = 0.f; Vex = 0.f; }
-            const float p = fmaf(tau0, x0v[i], x0p[i]) + Pex;
-            const float v = x0v[i] + Vex;
-            dps[i] = fmaf(P.sp[i], p, -P.gps[i]);
-            dvs[i] = fmaf(P.sv[i], v, -P.gvs[i]);
+            dps[i] = fmaf(P.sp[i], Pex, dps1[i]);
+            dvs[i] = fmaf(P.sv[i], Vex, dvs0[i]);
         }
 
         // ---- pass 2: dynamics + stage cost on the scaled state (src/point_mass_gpu.cu:97-107,
@@ -576,7 +588,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 template <int A, int NG>
 constexpr int packed_min_waves()
 {
+#ifdef MPPI_PK_WAVES
+    return MPPI_PK_WAVES;
+#else
     return NG * Dim<A>::BPG * 4 <= 32 ? 3 : 2;
+#endif
 }
 
 template <int A, int NG, bool SAMPLE>

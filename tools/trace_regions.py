@@ -74,3 +74,17 @@ for i, n in enumerate(names):
     print(f"{n:14s} {np.percentile(r, 10):8.0f} {med:8.0f} {np.percentile(r, 90):8.0f}   {med - prev:8.0f}")
     prev = med
 m.close()
+
+# ---- where the slow blocks are: duration (entry -> all tiles done) by XCD (round-robin over block
+#      index) and by dispatch half (second blocks of the CUs)
+t = buf.astype(np.int64)
+dur = (t[:, 9] - t[:, 0]).astype(np.float64)
+start = t[:, 0] - t[:, 0].min()
+print("block duration entry->all tiles: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f   (latest start %d)"
+      % (dur.min(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(), start.max()))
+idx = np.arange(len(dur))
+print("  by bid %% 8 (XCD):", " ".join("%.0f" % np.median(dur[idx % 8 == x]) for x in range(8)))
+half = len(dur) // 2
+print("  first half %.0f  second half %.0f" % (np.median(dur[:half]), np.median(dur[half:])))
+order = np.argsort(dur)
+print("  slowest blocks:", order[-12:], " fastest:", order[:12])
