@@ -95,6 +95,14 @@ int mppi_set_seed(mppi_engine* e, unsigned long long seed);
  * the reference exposes E as an I/O buffer, src/point_mass.cu:232,251). NULL = sample again. */
 int mppi_set_noise(mppi_engine* e, const float* noise);
 
+/* Whether the rollout materialises the sampled noise E in device memory (default 1: E is an
+ * observable of the reference, src/point_mass.cu:232,251, and its store is 94 % of the solve's HBM
+ * bytes).  With 0 the rollout writes the path costs and its partial sums only; E is a pure function
+ * of (seed, solve index, global sample index, step), and mppi_get_inf / mppi_get_data regenerate it
+ * -- bit for bit what would have been stored -- when asked.  Ignored by the strict kernel (which
+ * re-reads its noise) and in injected-noise mode. */
+int mppi_set_noise_store(mppi_engine* e, int on);
+
 /* Reproduce the reference's update_act sample-coverage defects: act_dim 3 sums
  * only the first 512*(K/768+1) samples (src/point_mass.cu:387,402,839-842); act_dim 1 sums only
  * the samples k with k even and (k/512) even, because the block trees stop one fold early

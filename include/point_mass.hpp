@@ -37,6 +37,7 @@ public:
     void set_seed(unsigned long long seed);
     void set_noise(const float* e);            // injected-noise mode, null = sample
     void set_ref_compat(bool on);
+    void set_noise_store(bool on);             // false: noise is regenerated on request, not stored
     void set_action_limit(const float* max_a);   // opt-in clamp to +-max_a[axis]; null = off
     void set_tuning(int chunks, bool strict, int max_blocks);
     mppi_engine* handle() { return engine_; }

@@ -156,6 +156,10 @@ class PointMassModel:
         E = _f32(E, self.K * self.T * self.A, "E")
         check(self._lib.mppi_set_noise(self._h, _fp(E)))
 
+    def set_noise_store(self, on):
+        """False: the rollout does not write the sampled noise to HBM; get_inf regenerates it."""
+        check(self._lib.mppi_set_noise_store(self._h, int(bool(on))))
+
     def set_ref_compat(self, on):
         check(self._lib.mppi_set_ref_compat(self._h, int(bool(on))))
 

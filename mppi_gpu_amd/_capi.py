@@ -35,6 +35,7 @@ SIGNATURES = {
     "mppi_set_seed": (C.c_int, [engine_p, C.c_ulonglong]),
     "mppi_set_noise": (C.c_int, [engine_p, c_float_p]),
     "mppi_set_ref_compat": (C.c_int, [engine_p, C.c_int]),
+    "mppi_set_noise_store": (C.c_int, [engine_p, C.c_int]),
     "mppi_set_action_limit": (C.c_int, [engine_p, c_float_p]),
     "mppi_set_tuning": (C.c_int, [engine_p, C.c_int, C.c_int, C.c_int]),
     "mppi_set_pipeline": (C.c_int, [engine_p, C.c_int]),

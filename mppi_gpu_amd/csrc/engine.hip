@@ -127,6 +127,10 @@ struct mppi_engine {
     unsigned int* d_tickets = nullptr; // combine arrival counters
     float* d_Einj = nullptr;    // injected noise, [K][T][A]
     bool injected = false, inj_dirty = false;
+    bool store_noise = true;    // sampled noise is materialised in d_Eint (mppi_set_noise_store)
+    bool last_stored = true;    // ... was, by the last rollout; if not, get_inf regenerates it from
+    unsigned long long last_seed = 0;       // (seed, solve index, sample offset, sigma) of that rollout
+    float last_sigma[4] = {0.f, 0.f, 0.f, 0.f};
     float* d_scratch = nullptr; // export / trace / weights scratch
     size_t scratch_floats = 0;
 
@@ -391,6 +395,7 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.NGT = e->NGT;
     a.TPW = e->TPW;
     a.pk_has_cg = 0;
+    a.store_e = (e->store_noise || e->strict) ? 1 : 0;   // (the strict kernel re-reads its noise)
     for (int i = 0; i < e->A; ++i) {
         // scaled state of the packed kernel: d_p = sp (p - g_p), d_v = sv (v - g_v); a zero weight
         // gets the scale 2^-60, whose square vanishes against any cost (and is exact to undo)
@@ -626,6 +631,9 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     e->last_E = Ecur;
     e->last_lay = lay;
     e->last_idx = e->solve_idx;
+    e->last_stored = e->injected || e->store_noise || e->strict;
+    e->last_seed = e->seed;
+    for (int i = 0; i < 4; ++i) e->last_sigma[i] = e->sigma[i];
     memcpy(e->x0_last, e->x0, sizeof e->x0);
     return MPPI_OK;
 }
@@ -989,8 +997,12 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     if (noise) {
         const size_t n = (size_t)e->K * e->T * e->A;
         if ((rc = ensure_scratch(e, n))) return rc;
-        HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_lay,
-                                         e->stream));
+        if (e->last_stored)
+            HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_lay,
+                                             e->stream));
+        else     // not materialised by the rollout: the same counters give the same bits again
+            HIPCHK(mppi::launch_regen_noise(e->A, e->d_scratch, e->K, e->T, e->last_seed,
+                                            e->last_idx, e->k_offset, e->last_sigma, e->stream));
         {
         int rc_ = settle(e);
         if (rc_) return rc_;
@@ -999,12 +1011,22 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     }
     if (x_all) {
         const size_t n = (size_t)e->K * (e->T + 1) * e->S;
+        const size_t ne = e->last_stored ? 0 : (size_t)e->K * e->T * e->A;
         // controls and x0 the last rollout used: U buffer of parity last_idx, x0_last
-        if ((rc = ensure_scratch(e, n + 8))) return rc;
+        if ((rc = ensure_scratch(e, n + 8 + ne))) return rc;
         float* d_x0 = e->d_scratch + n;
         HIPCHK(hipMemcpy(d_x0, e->x0_last, 8 * sizeof(float), hipMemcpyHostToDevice));
-        HIPCHK(mppi::launch_trace_states(e->A, e->last_E, e->d_U + (e->last_idx & 1ull) * e->TA,
-                                         d_x0, e->d_scratch, e->K, e->T, e->last_lay, e->dt, e->B0,
+        const float* Esrc = e->last_E;
+        mppi::ELayout lay = e->last_lay;
+        if (!e->last_stored) {       // regenerate the noise next to the trace, in E[k][t][a] order
+            float* d_e = e->d_scratch + n + 8;
+            HIPCHK(mppi::launch_regen_noise(e->A, d_e, e->K, e->T, e->last_seed, e->last_idx,
+                                            e->k_offset, e->last_sigma, e->stream));
+            Esrc = d_e;
+            lay = mppi::ELayout{2, 1, 0, 0, e->T, 0};
+        }
+        HIPCHK(mppi::launch_trace_states(e->A, Esrc, e->d_U + (e->last_idx & 1ull) * e->TA,
+                                         d_x0, e->d_scratch, e->K, e->T, lay, e->dt, e->B0,
                                          e->stream));
         {
         int rc_ = settle(e);
@@ -1060,6 +1082,18 @@ int mppi_set_noise(mppi_engine* e, const float* noise)
     HIPCHK(hipMemcpy(e->d_Einj, noise, n * sizeof(float), hipMemcpyHostToDevice));
     e->injected = true;
     e->inj_dirty = true;
+    return MPPI_OK;
+}
+
+int mppi_set_noise_store(mppi_engine* e, int on)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    {
+        int rc_ = flush_pending(e);
+        if (rc_) return rc_;
+    }
+    e->store_noise = on != 0;
+    e->args_valid = false;
     return MPPI_OK;
 }
 

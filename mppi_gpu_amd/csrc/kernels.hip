@@ -188,6 +188,7 @@ __device__ __forceinline__ size_t eint_index(long long kloc, int t, int a, const
 {
     const int n = t * A + a;         // flat normal index of the sample
     const int b = n >> 2;            // Philox block
+    if (L.packed == 2) return ((size_t)kloc * L.NGT + t) * A + a;      // plain [k][t][a], NGT = T
     if (L.packed) {
         constexpr int BPG = Dim<A>::BPG;
         const long long tile = kloc / L.TPW;                  // one wavefront = TPW trajectories
@@ -264,6 +265,31 @@ __global__ void k_trace_states(const float* Eint, const float* U, const float* x
         for (int i = 0; i < A; ++i) {
             xk[(size_t)(t + 1) * S + i] = p[i];
             xk[(size_t)(t + 1) * S + A + i] = v[i];
+        }
+    }
+}
+
+// E[k][t][a] regenerated from the counters (noise not materialised by the rollout)
+template <int A>
+__global__ void k_regen_noise(float* E, int K, int TA, int NBT, unsigned long long seed,
+                              unsigned long long solve_idx, long long k_offset, float s0, float s1,
+                              float s2, float s3)
+{
+    const float sig[4] = {s0, s1, s2, s3};
+    const size_t total = (size_t)K * NBT;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const long long k = (long long)(idx / NBT);
+        const int b = (int)(idx - (size_t)k * NBT);
+        const uint4 r = PhiloxAt::block(solve_idx * (unsigned long long)NBT + (unsigned long long)b,
+                                        (unsigned long long)(k_offset + k), seed);
+        float z[4];
+        box_muller_hw(r.x, r.y, z[0], z[1]);
+        box_muller_hw(r.z, r.w, z[2], z[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = b * 4 + i;
+            if (n < TA) E[(size_t)k * TA + n] = sig[n % A] * z[i];
         }
     }
 }
@@ -545,6 +571,22 @@ hipError_t launch_trace_states(int A, const float* Eint, const float* U, const f
         case 2: hipLaunchKernelGGL(k_trace_states<2>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
         case 3: hipLaunchKernelGGL(k_trace_states<3>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
         case 4: hipLaunchKernelGGL(k_trace_states<4>, dim3(grid), dim3(256), 0, st, Eint, U, x0, X, K, T, lay, dt, B0); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_regen_noise(int A, float* E, int K, int T, unsigned long long seed,
+                              unsigned long long solve_idx, long long k_offset, const float* sg,
+                              hipStream_t st)
+{
+    const int TA = T * A, NBT = (TA + 3) / 4;
+    const int grid = copy_grid((size_t)K * NBT);
+    switch (A) {
+        case 1: hipLaunchKernelGGL(k_regen_noise<1>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
+        case 2: hipLaunchKernelGGL(k_regen_noise<2>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
+        case 3: hipLaunchKernelGGL(k_regen_noise<3>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
+        case 4: hipLaunchKernelGGL(k_regen_noise<4>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -75,6 +75,9 @@ struct RolloutArgs {
     // d_v' = d_v + k3 a, stage cost d_p'^2 + d_v'^2; computed on the host in double precision
     float pk_sp[4], pk_sv[4], pk_k1[4], pk_k2[4], pk_k3[4], pk_cg[4], pk_gps[4], pk_gvs[4];
     int pk_has_cg;         // some velocity goal != 0
+    int store_e;           // 0: the sampled noise is not written to Eint (mppi_set_noise_store);
+                           // it is a pure function of (seed, solve, sample, step) and is
+                           // regenerated on request (launch_regen_noise)
     float x0[8];           // host copy of the current state (travels by value in RolloutHot)
     // read only on the riding path (DeferredCombine), kept here so that they cost no kernel
     // argument registers: the tagged finished controls and the device watchdog words
@@ -240,7 +243,7 @@ struct LaunchTiming {
 // Where sample k's normal (t, a) sits in the noise buffer: the row-aligned layout is described by
 // (C, nq), the packed one by (NG, NGT, TPW) with nq = NG * blocks-per-group.
 struct ELayout {
-    int packed;
+    int packed;            // 0 row-aligned, 1 packed, 2 plain E[k][t][a] (regenerated noise)
     int C, nq;
     int NG, NGT, TPW;
 };
@@ -298,6 +301,11 @@ hipError_t launch_trace_states(int A, const float* Eint, const float* U_rollout,
                                hipStream_t st);
 hipError_t launch_weights(const float* cost, const DevState* dev, float lambda, float* wts,
                           int K, hipStream_t st);
+// E[k][t][a] of solve `solve_idx` straight from the Philox counters: the very device functions the
+// rollout kernels draw with, hence the very bits they would have stored
+hipError_t launch_regen_noise(int A, float* E_ktA, int K, int T, unsigned long long seed,
+                              unsigned long long solve_idx, long long k_offset, const float* sigma4,
+                              hipStream_t st);
 
 // launch with or without dispatch timing
 #define MPPI_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                       \

@@ -66,6 +66,7 @@ void PointMassModel::set_params(float lambda, const float* sigma, const float* i
 void PointMassModel::set_seed(unsigned long long seed) { MPPI_CALL_CONST(mppi_set_seed(engine_, seed)); }
 void PointMassModel::set_noise(const float* e) { MPPI_CALL_CONST(mppi_set_noise(engine_, e)); }
 void PointMassModel::set_ref_compat(bool on) { MPPI_CALL_CONST(mppi_set_ref_compat(engine_, on)); }
+void PointMassModel::set_noise_store(bool on) { MPPI_CALL_CONST(mppi_set_noise_store(engine_, on)); }
 void PointMassModel::set_action_limit(const float* max_a)
 {
     MPPI_CALL_CONST(mppi_set_action_limit(engine_, max_a));

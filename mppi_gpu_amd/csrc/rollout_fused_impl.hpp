@@ -108,6 +108,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
     P.dt2 = P.dt * P.dt;
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
+    const bool store_e = g.store_e != 0;     // wave-uniform: noise materialised in HBM or not
     float* const cost_out = g.cost;
 
     // chunk geometry of this lane (same for every tile group)
@@ -165,7 +166,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         box_muller_hw(r.z, r.w, z[2], z[3]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
-                        if (c * nq + q < NBT) {    // blocks past the horizon are not stored
+                        if (store_e && c * nq + q < NBT) {   // blocks past the horizon are not stored
                             // Write-through store (sc0 sc1): E is not read again by this
                             // launch, and what a plain store leaves dirty in the XCD L2s -- all
                             // 16 MB at C2 -- is written back at the END of the kernel, where

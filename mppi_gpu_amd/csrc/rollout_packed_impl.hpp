@@ -105,6 +105,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
+    const bool store_e = g.store_e != 0;     // wave-uniform: noise materialised in HBM or not
     float* const cost_out = g.cost;
 
     // ---- where this lane's group slots sit (the same for every tile) ---------------------------
@@ -200,7 +201,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 // (one group at a time: left alone, hipcc interleaves the Philox chains of all
                 //  groups of the lane and runs out of registers; the VALU is saturated by one)
                 __builtin_amdgcn_sched_barrier(0);
-                if (hd ? valid_h : valid_t) {      // idle slots and samples >= K store nothing
+                if (store_e && (hd ? valid_h : valid_t)) {   // idle slots, samples >= K: no store
 #pragma unroll
                     for (int b = 0; b < BPG; ++b) {
                         const int q = gi * BPG + b;

@@ -14,9 +14,10 @@ inputs.  Floating point, so tolerances are stated here:
 The U criterion is |U_gpu - U_oracle|_inf <= 1e-5 * max(|U_oracle|_inf, sigma): element-wise
 relative error is meaningless where a control crosses zero.  The strict kernel meets it always,
 and so does the fused (benchmarked) kernel wherever the weights average over enough samples:
-the PLAIN 1e-5 bar is asserted for every case whose effective sample size 1/sum(w^2) is at least
-ESS_PLAIN.  Only below that (nearly one-hot weights: the underflow and cost-ramp cases, tiny
-batches) the fused kernel gets max(that, 4 ulp(max cost)/lambda * max|E|): two correct fp32
+the PLAIN 1e-5 bar is asserted for the BASELINE-size cases (configs 2, 3, 4 whole and 4's last
+shard: they achieve 1e-7 .. 3e-6) and for every case whose effective sample size 1/sum(w^2) is at
+least ESS_PLAIN.  Only below that (nearly one-hot weights at lambda = 1: the underflow and
+cost-ramp cases, tiny batches, the random sweep) the fused kernel gets max(that, 4 ulp(max cost)/lambda * max|E|): two correct fp32
 evaluations of a path cost of a few hundred differ by a few ulp (1.5e-5 each at 230), the
 weights by that amount RELATIVE, and with a handful of effective samples nothing averages the
 difference out.  The same holds between the reference's own nvcc build (FMA-contracted) and its
@@ -69,7 +70,9 @@ def _dump_records():
 atexit.register(_dump_records)
 
 
-def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGMA):
+def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGMA, plain=False):
+    """plain=True: the plain 1e-5 bar whatever the effective sample size (the BASELINE-size
+    cases: they hold it with a margin, profiles/parity_r02.json)."""
     wref = ref["weights"].astype(np.float64)
     ess = float(1.0 / np.sum(wref * wref)) if wref.sum() > 0 else 0.0
     scale0 = max(float(np.abs(ref["U"]).max()), SIGMA)
@@ -82,7 +85,7 @@ def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGM
                                        / np.maximum(ref["weights"], 1e-30)
                                        * (ref["weights"] > 1e-12))),
            "nabla_rtol": float(abs(inf["nabla"] - ref["nabla"]) / ref["nabla"]),
-           "plain_bar": bool(cost_exact or ess >= ESS_PLAIN)}
+           "plain_bar": bool(cost_exact or plain or ess >= ESS_PLAIN)}
     _RECORDS.append(rec)
     if cost_exact:
         assert np.array_equal(inf["cost"], ref["cost"]), f"{tag}: cost not bit-exact"
@@ -99,7 +102,7 @@ def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGM
                                atol=1e-12, err_msg=tag)
     scale = max(float(np.abs(ref["U"]).max()), SIGMA)
     tol = 1e-5 * scale
-    if not cost_exact and ess < ESS_PLAIN:        # nearly one-hot weights only (module docstring)
+    if not cost_exact and not plain and ess < ESS_PLAIN:   # nearly one-hot weights only (docstring)
         if "e" in inf:
             emax = float(np.abs(inf["e"]).max())
         tol = max(tol, 4 * float(np.spacing(np.float32(ref["cost"].max()))) / lam * emax)
@@ -245,6 +248,33 @@ def test_packing_is_refused_where_it_does_not_apply(gpu):
     c = ol.make_case(3, 1, 200, seed=3)
     with _model(gpu, 3, 12000, 200, c) as m:             # many tiles per block: packed by itself
         assert m.geometry()["packed"] and m.geometry()["trajectories_per_wave"] == 5
+
+
+@pytest.mark.parametrize("A,K,T,packing", [(3, 12000, 200, 0), (3, 1500, 200, -1), (2, 3000, 200, 8),
+                                            (2, 10000, 200, 0), (1, 700, 33, 0)])
+def test_noise_not_materialised_is_regenerated_bit_for_bit(gpu, A, K, T, packing):
+    """mppi_set_noise_store(0): the rollout stores no noise (94 % fewer HBM bytes); the solve is
+    the same bits, and the noise get_inf hands out -- regenerated from the Philox counters -- equals
+    what the storing rollout wrote, bit for bit; so does the state trace computed from it."""
+    c = ol.make_case(A, 1, T, seed=17, u_scale=0.05)
+    out = []
+    for store in (True, False):
+        with _model(gpu, A, K, T, c) as m:
+            if packing:
+                m.set_packing(packing)
+            m.set_noise_store(store)
+            m.set_seed(99)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.get_act()
+            act = m.get_act()                       # second solve: solve index 1 in the counters
+            inf = m.get_inf(x=(K <= 3000))
+            out.append((act, inf))
+    (a1, i1), (a0, i0) = out
+    assert np.array_equal(a1, a0) and np.array_equal(i1["u"], i0["u"])
+    assert np.array_equal(i1["cost"], i0["cost"])
+    assert np.array_equal(i1["e"], i0["e"]), "regenerated noise differs from stored noise"
+    if "x" in i1:
+        assert np.array_equal(i1["x"], i0["x"])
 
 
 def test_states_trace_matches_oracle(gpu):
@@ -848,7 +878,8 @@ def test_full_size_parity_and_properties(gpu, A, K, T, k_offset):
         geo = m.geometry()
     # (1) the oracle, run on the very noise the device drew, reproduces the solve
     ref = ol.solve(c["x0"], c["U"], inf["e"], c["goal"], c["w"], c["dt"])
-    _check_solve(act, inf, ref, cost_exact=False, tag=f"full A{A} K{K} off={k_offset} {geo}")
+    _check_solve(act, inf, ref, cost_exact=False, tag=f"full A{A} K{K} off={k_offset} {geo}",
+                 plain=True)
     if k_offset is not None:
         # the shard draws the noise of the GLOBAL sample indices: rows 0..63 of the shard are
         # rows k_offset.. of the host statement of the stream
