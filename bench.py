@@ -136,6 +136,72 @@ def committed_profile(name):
         return None
 
 
+def roofline_entry(workload, K, T, A, geo, riding, k_ms, k_n, c_ms):
+    """The `roofline` object of one workload from the live event timing of its rollout launches.
+    PMC counters cannot be collected from inside the timed process: `traffic`, the rocprofv3
+    kernel duration and the VALU figures come from the COMMITTED summaries of this workload and
+    geometry (tools/traffic.sh, tools/kt.sh, tools/alu.sh -> profiles/), and are labelled so."""
+    kind = "ride" if riding else "plain"
+    shape = f"packed{geo['groups_per_lane']}" if geo["packed"] else f"chunks={geo['chunks']}"
+    prof_key = f"{workload}:{shape}:{kind}"
+    ab = algorithmic_bytes_rollout(K, T, A)
+    ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic = traffic_src = None
+    tj = committed_profile(PROFILE_TRAFFIC)
+    if tj and not geo["strict"]:
+        ent = tj["entries"].get(prof_key)
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_src = (f"committed profile profiles/{PROFILE_TRAFFIC} (rocprofv3 --pmc "
+                           "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command); not "
+                           "measured in this run")
+    base = "k_rollout_packed" if geo["packed"] else "k_rollout_fused"
+    kname = ("k_rollout_stream" if geo["strict"] else
+             (base + "_ride" if geo["packed"] else "k_rollout_ride")
+             + " (rollout of solve j + combine of solve j-1 in one launch)" if riding
+             else base)
+    roof = {"bound": "hbm", "kernel": kname,
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
+            "kernel_ms_source": "HIP events stamped on the dispatch (hipExtLaunchKernelGGL), "
+                                "second launch of each stamped pair, inside the timed region",
+            "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
+    aj = committed_profile(PROFILE_ALU)
+    if aj and not geo["strict"]:
+        ent = aj["entries"].get(prof_key)
+        if ent:
+            # rocprofv3's own average duration of the same kernel (profiled runs clock a few per
+            # cent lower than this un-profiled one) and the fraction it gives
+            if ent.get("kernel_ms_rocprof"):
+                roof["kernel_ms_rocprof"] = ent["kernel_ms_rocprof"]
+                roof["frac_rocprof"] = round(ab / (ent["kernel_ms_rocprof"] * 1e-3) / 1e9
+                                             / HBM_PEAK_GBS, 4)
+            roof["alu"] = dict(ent["alu"], source=f"committed profile profiles/{PROFILE_ALU} "
+                               "(rocprofv3 --pmc SQ instruction counters, same command); not "
+                               "measured in this run")
+    return roof
+
+
+def timed_engine_run(m, n_warm, n, every=8):
+    """n solves enqueued back to back on engine m: (seconds per solve, rollout kernel ms, launches
+    stamped, combine kernel ms)."""
+    for _ in range(n_warm):
+        m.solve_async()
+    m.sync_act()
+    m.set_profiling(every)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.solve_async()
+    m.sync_act()
+    dt = (time.perf_counter() - t0) / n
+    k_ms, k_n = m.kernel_ms(0)
+    c_ms, _ = m.kernel_ms(1)
+    m.set_profiling(0)
+    return dt, k_ms, k_n, c_ms
+
+
 def spawn_ranks(n_gpus):
     """--gpus N without a launcher: start the N rank processes (one per GPU) before anything here
     touches a GPU, pass their output through and exit with the worst of their codes."""
@@ -286,55 +352,12 @@ def main():
     roof = None
     # mode 0 lets the combine ride in the next rollout launch while launches are short (at most two
     # tiles per block, engine.hip enqueue_rollout); longer ones launch it on its own
-    n_tiles = geo["tile_groups"]
     riding = (args.pipeline == 0 and not args.strict and not args.blocking
-              and n_tiles <= 2 * geo["grid"])
-    kind = "ride" if riding else "plain"
-    shape = f"packed{geo['groups_per_lane']}" if geo["packed"] else f"chunks={geo['chunks']}"
-    prof_key = f"{args.workload}:{shape}:{kind}"
+              and geo["tile_groups"] <= 2 * geo["grid"])
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
-        ab = algorithmic_bytes_rollout(K, T, A)
-        ach = ab / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # PMC counters cannot be collected from inside the timed process: traffic, the rocprofv3
-        # kernel duration and the VALU figures come from the COMMITTED summaries of this
-        # workload/geometry (tools/traffic.sh, tools/kt.sh, tools/alu.sh), and are labelled so
-        traffic = traffic_src = None
-        tj = committed_profile(PROFILE_TRAFFIC)
-        if tj and not geo["strict"]:
-            ent = tj["entries"].get(prof_key)
-            if ent:
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_src = (f"committed profile profiles/{PROFILE_TRAFFIC} (rocprofv3 --pmc "
-                               "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command); not "
-                               "measured in this run")
-        base = "k_rollout_packed" if geo["packed"] else "k_rollout_fused"
-        kname = ("k_rollout_stream" if geo["strict"] else
-                 (base + "_ride" if geo["packed"] else "k_rollout_ride")
-                 + " (rollout of solve j + combine of solve j-1 in one launch)" if riding
-                 else base)
-        roof = {"bound": "hbm", "kernel": kname,
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": ab, "kernel_ms": round(k_ms, 5),
-                "kernel_ms_source": "HIP events stamped on the dispatch (hipExtLaunchKernelGGL), "
-                                    "second launch of each stamped pair, inside the timed region",
-                "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
-        aj = committed_profile(PROFILE_ALU)
-        if aj and not geo["strict"]:
-            ent = aj["entries"].get(prof_key)
-            if ent:
-                # rocprofv3's own average duration of the same kernel (profiled runs clock ~3-6 %
-                # lower than this un-profiled one) and the fraction it gives
-                if ent.get("kernel_ms_rocprof"):
-                    roof["kernel_ms_rocprof"] = ent["kernel_ms_rocprof"]
-                    roof["frac_rocprof"] = round(ab / (ent["kernel_ms_rocprof"] * 1e-3) / 1e9
-                                                 / HBM_PEAK_GBS, 4)
-                roof["alu"] = dict(ent["alu"], source=f"committed profile profiles/{PROFILE_ALU} "
-                                   "(rocprofv3 --pmc SQ instruction counters, same command); not "
-                                   "measured in this run")
+        roof = roofline_entry(args.workload, K, T, A, geo, riding, k_ms, k_n, c_ms)
         if riding and sharded is None:
             # for reference, outside the timed region: the two kernels on their own (eager mode,
             # one rollout launch + one combine launch per solve)
@@ -347,6 +370,7 @@ def main():
             c2_ms, _ = m.kernel_ms(1)
             m.set_profiling(0)
             m.set_pipeline(0)
+            ab = algorithmic_bytes_rollout(K, T, A)
             roof["solo"] = {"rollout_kernel_ms": round(r_ms, 5), "combine_kernel_ms": round(c2_ms, 5),
                             "rollout_frac": round(ab / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                             if r_ms > 0 else None}
@@ -381,8 +405,35 @@ def main():
                    "what": "PointMassModel.get_act() through the Python binding: launch, solve, "
                            "wait for the action in host memory (reference src/main.cu:329-332)"}
 
-    # ---- config 4's strong-scaling leg (K = 1e6 global) when run on several GPUs ---------------
     extra = {}
+    if N == 1 and sharded is None and not (args.blocking or args.inject or args.strict or args.no_events):
+        # ---- the same workload with the noise NOT materialised (mppi_set_noise_store(0)): a
+        #      reported variant, never the headline (E is an observable of the reference) --------
+        m.set_noise_store(False)
+        dt_v, k_v, k_nv, _ = timed_engine_run(m, 100, min(args.steps, 500))
+        m.set_noise_store(True)
+        extra["noise_not_materialised"] = {
+            "what": "mppi_set_noise_store(0): the rollout stores path costs and partial sums only; "
+                    "get_inf regenerates the noise bit for bit from the Philox counters (tested)",
+            "ms_per_step": dt_v * 1e3, "value": K / dt_v, "rollout_kernel_ms": round(k_v, 5),
+            "hbm_bytes_per_launch_algorithmic": 4 * K,
+            "bound": "valu (no HBM stream left: see roofline.alu of the storing kernel)"}
+        # ---- BASELINE configs[2] (point_mass3d, K = 1e5) in the same run: the long-launch regime,
+        #      where the rollout kernel's roofline fraction is the meaningful one ------------------
+        if args.workload == "c2":
+            A3, K3, T3, desc3 = WORKLOADS["c3"]
+            c3 = make_inputs(A3, T3)
+            m3 = PointMassModel(K3, T3, float(c3["dt"]), 2 * A3, A3)
+            m3.set_seed(0)
+            m3.memcpy_set_data(c3["x0"], c3["U"], c3["goal"], c3["w"])
+            geo3 = m3.geometry()
+            dt3, k3, kn3, cm3 = timed_engine_run(m3, 60, 400)
+            riding3 = geo3["tile_groups"] <= 2 * geo3["grid"]
+            extra["c3"] = {"workload": desc3, "ms_per_step": dt3 * 1e3, "value": K3 / dt3,
+                           "unit": "rollouts/s", "steps": 400, "geometry": geo3,
+                           "roofline": roofline_entry("c3", K3, T3, A3, geo3, riding3, k3, kn3, cm3)}
+            m3.close()
+    # ---- config 4's strong-scaling leg (K = 1e6 global) when run on several GPUs ---------------
     if N > 1 and not args.rehearse_one_gpu and args.workload != "c4":
         from mppi_gpu_amd.sharded import ShardedPointMassModel
         A4, T4, K4 = 3, 200, 1_000_000
