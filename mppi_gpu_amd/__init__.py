@@ -97,10 +97,13 @@ class PointMassModel:
         check(self._lib.mppi_get_x(self._h, _fp(x)))
         return x
 
-    def get_act(self):
-        """One full MPPI solve; reference src/point_mass.cu:129-203. Returns next_act[A]."""
-        act = np.empty(self.A, np.float32)
-        check(self._lib.mppi_get_act(self._h, _fp(act)))
+    def get_act(self, out=None):
+        """One full MPPI solve; reference src/point_mass.cu:129-203. Returns next_act[A]
+        (written into `out`, a float32 array of A elements, when given: no allocation per call)."""
+        act = np.empty(self.A, np.float32) if out is None else out
+        rc = self._lib.mppi_get_act(self._h, _fp(act))
+        if rc != 0:
+            check(rc)
         return act
 
     def get_u(self):

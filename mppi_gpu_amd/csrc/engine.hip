@@ -849,7 +849,6 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
     e->args_valid = false;
     e->solve_idx = 0;   // the reference re-seeds its generators here (src/point_mass.cu:780)
     e->have_solve = false;
-    HIPCHK(hipMemcpy(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_U, u, (size_t)e->TA * sizeof(float), hipMemcpyHostToDevice));
     e->data_set = true;
     return MPPI_OK;
@@ -858,20 +857,17 @@ int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* 
 int mppi_set_x(mppi_engine* e, const float* x0)
 {
     if (!e || !x0) return fail(MPPI_EINVAL, "null argument");
+    // Host-only: the state travels BY VALUE in the arguments of the next rollout launch, so solves
+    // already enqueued keep the state they were enqueued with and nothing touches the GPU here
+    // (the reference copies to the device and runs set_x_kernel over K rows, src/point_mass.cu:482-486)
     for (int i = 0; i < e->S; ++i) e->x0[i] = x0[i];
-    // ordered behind the solves already enqueued on the engine's stream
-    HIPCHK(hipMemcpyAsync(e->d_state->x0, e->x0, sizeof e->x0, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
     return MPPI_OK;
 }
 
 int mppi_get_x(mppi_engine* e, float* x0)
 {
     if (!e || !x0) return fail(MPPI_EINVAL, "null argument");
-    float tmp[8];
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(tmp, e->d_state->x0, sizeof tmp, hipMemcpyDeviceToHost));
-    for (int i = 0; i < e->S; ++i) x0[i] = tmp[i];
+    for (int i = 0; i < e->S; ++i) x0[i] = e->x0[i];      // the engine is the only writer
     return MPPI_OK;
 }
 

@@ -35,10 +35,12 @@ namespace mppi {
 // (reference src/point_mass_gpu.cu:111-121): bit-identical to the serial host arithmetic.
 // Slow by design (noise is re-read for the weighted sums); it is the parity anchor.
 // ------------------------------------------------------------------------------------------
+struct X0Arg { float v[8]; };      // the current state travels by value (mppi_set_x is host-only)
+
 template <int A, bool SAMPLE>
 __global__ void __launch_bounds__(kRolloutThreads)
 k_rollout_stream(const RolloutArgs* __restrict__ gp, float* __restrict__ Eint,
-                 const unsigned long long solve_idx)
+                 const unsigned long long solve_idx, const X0Arg x0)
 {
     const RolloutArgs& g = *gp;      // Eint travels by value: the device copy does not hold it
     constexpr int SG = Dim<A>::SG;
@@ -71,8 +73,8 @@ k_rollout_stream(const RolloutArgs* __restrict__ gp, float* __restrict__ Eint,
         float p[A], v[A];
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            p[i] = g.dev->x0[i];
-            v[i] = g.dev->x0[A + i];
+            p[i] = x0.v[i];
+            v[i] = x0.v[A + i];
         }
         float cost = 0.0f;
         for (int gi = 0; gi < n_groups; ++gi) {
@@ -478,12 +480,14 @@ static hipError_t launch_stream_a(bool sample, int grid, const RolloutArgs& a, h
                                   LaunchTiming tm)
 {
     const size_t lds = rollout_lds_bytes(a.NBTp, a.nq * 4);
+    X0Arg x0;
+    for (int i = 0; i < 8; ++i) x0.v[i] = a.x0[i];
     if (sample)
         MPPI_LAUNCH((k_rollout_stream<A, true>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
-                    a.dev_copy, a.Eint, a.solve_idx);
+                    a.dev_copy, a.Eint, a.solve_idx, x0);
     else
         MPPI_LAUNCH((k_rollout_stream<A, false>), dim3(grid), dim3(kRolloutThreads), lds, st, tm,
-                    a.dev_copy, a.Eint, a.solve_idx);
+                    a.dev_copy, a.Eint, a.solve_idx, x0);
     return hipGetLastError();
 }
 
