@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Turn what tools/r2_profiles.sh left under gpurun_out/ into the committed summaries under
+profiles/ (round 2): kernel-trace stats, SQ counters per wave, traffic_r02.json, alu_r02.json,
+bench lines, parity table, micro-benchmark tables.  Run in the authoring container after the GPU
+call; no GPU needed."""
+import csv
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out")
+DST = os.path.join(ROOT, "profiles")
+
+# (profile tag, bench workload key, kernel-name substring, roofline key suffix)
+KEYS = [
+    ("r2_c2", "c2:chunks=16:ride", "k_rollout_ride<2"),
+    ("r2_c2e", "c2:chunks=16:plain", "k_rollout_fused<2"),
+    ("r2_c2", "c2:combine_small", "k_combine_small"),
+    ("r2_c3", "c3:packed4:plain", "k_rollout_packed<3"),
+    ("r2_c3", "c3:combine_small", "k_combine_small"),
+]
+# issue cost of a wave64 instruction in SIMD cycles at the nominal 2.4 GHz, measured with
+# tools/ubench_issue on MI355X at >= 4 waves per SIMD and ILP >= 2 (profiles/r02_ubench_issue.txt)
+COST = {"INT64": 6.3, "TRANS_F32": 8.4, "BITOP3": 4.2, "OTHER": 2.3}
+N_SIMD, F_NOMINAL = 1024, 2.4e9
+
+
+def rocprof_avg_us(tag, sub):
+    for r in csv.DictReader(open(os.path.join(SRC, "prof", f"{tag}_stats.csv"))):
+        if sub in r["Name"]:
+            return float(r["AverageNs"]) * 1e-3, int(r["Calls"])
+    return None, 0
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    traffic = {"note": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+               "passes with --kernel-trace only, tools/traffic.sh); FETCH_SIZE doubled per "
+               "guides/MI355X_MICROARCH.md (gfx950 counts wide coalesced reads at half), WRITE_SIZE "
+               "exact for dwordx4 streaming stores. ':ride' = the launch that also carries the "
+               "previous solve's combine, ':plain' = the rollout alone", "entries": {}}
+    alu = {"note": "VALU side of the roofline from rocprofv3 --pmc SQ instruction counters (tools/alu.sh) "
+           "and the rocprofv3 --kernel-trace --stats duration of the same command (tools/kt.sh). "
+           "alu.achieved = sum over instruction classes of count x measured issue cycles, divided by "
+           "the SIMD cycles of the launch (1024 SIMDs x duration x 2.4 GHz nominal); classes and "
+           "costs: v_mad_u64_u32 (SQ_INSTS_VALU_INT64) %.1f, transcendentals %.1f, v_bitop3_b32 %.1f "
+           "(not counted separately by the PMC: taken as one per v_mad_u64_u32, two of each per "
+           "Philox round), every other VALU instruction %.1f cycles (tools/ubench_issue.hip, "
+           "profiles/r02_ubench_issue.txt)" % (COST["INT64"], COST["TRANS_F32"], COST["BITOP3"],
+                                               COST["OTHER"]),
+           "entries": {}}
+    for tag, key, sub in KEYS:
+        tj = json.load(open(os.path.join(SRC, "prof", f"{tag}_traffic.json")))
+        for name, v in tj["kernels"].items():
+            if sub in name:
+                traffic["entries"][key] = {"kernel": name, "hbm_bytes_per_launch": round(v["hbm_bytes"]),
+                                           "fetch_bytes_corrected": round(v["fetch_bytes_corrected_x2"]),
+                                           "write_bytes": round(v["write_bytes"])}
+        aj = json.load(open(os.path.join(SRC, "prof", f"{tag}_alu.json")))
+        us, calls = rocprof_avg_us(tag, sub)
+        for name, v in aj["kernels"].items():
+            if sub not in name:
+                continue
+            n_all, n64, ntr = v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU_INT64"], v["SQ_INSTS_VALU_TRANS_F32"]
+            nb3 = n64 if "rollout" in name else 0.0
+            cyc = (n64 * COST["INT64"] + ntr * COST["TRANS_F32"] + nb3 * COST["BITOP3"]
+                   + (n_all - n64 - ntr - nb3) * COST["OTHER"])
+            simd_cycles = N_SIMD * us * 1e-6 * F_NOMINAL
+            alu["entries"][key] = {
+                "kernel": name, "kernel_ms_rocprof": round(us * 1e-3, 6), "rocprof_calls": calls,
+                "alu": {"bound": "valu", "achieved": round(cyc / simd_cycles, 4), "peak": 1.0,
+                        "unit": "fraction of the launch's VALU issue cycles",
+                        "valu_instructions_per_launch": round(n_all),
+                        "v_mad_u64_u32": round(n64), "transcendental": round(ntr),
+                        "fma_f32": round(v["SQ_INSTS_VALU_FMA_F32"]), "add_f32": round(v["SQ_INSTS_VALU_ADD_F32"]),
+                        "mul_f32": round(v["SQ_INSTS_VALU_MUL_F32"]),
+                        "issue_cycles_model": round(cyc)}}
+    json.dump(traffic, open(os.path.join(DST, "traffic_r02.json"), "w"), indent=1)
+    json.dump(alu, open(os.path.join(DST, "alu_r02.json"), "w"), indent=1)
+    for tag in ("c2", "c2e", "c3", "c4"):
+        shutil.copy(os.path.join(SRC, "prof", f"r2_{tag}_stats.csv"),
+                    os.path.join(DST, f"r02_{tag}_kernel_stats.csv"))
+    for tag in ("c2", "c2e", "c3"):
+        shutil.copy(os.path.join(SRC, "prof", f"r2_{tag}_pmc.txt"), os.path.join(DST, f"r02_{tag}_pmc_sq.txt"))
+    for f in ("bench_c2", "bench_c3", "bench_c4shard", "bench_c4full", "bench_c1", "bench_c2_sharded_1rank"):
+        line = open(os.path.join(SRC, "r2", f + ".json")).read().strip().splitlines()[-1]
+        json.dump(json.loads(line), open(os.path.join(DST, f"r02_{f}.json"), "w"), indent=1)
+    for f in ("ubench_issue.txt", "ubench_noise.txt", "latency_probe.txt"):
+        txt = [l for l in open(os.path.join(SRC, "r2", f)).read().splitlines() if "warning" not in l]
+        open(os.path.join(DST, "r02_" + f), "w").write("\n".join(txt) + "\n")
+    if os.path.exists(os.path.join(SRC, "parity_r02.json")):
+        shutil.copy(os.path.join(SRC, "parity_r02.json"), os.path.join(DST, "parity_r02.json"))
+    for k, v in alu["entries"].items():
+        print(k, v["kernel_ms_rocprof"], v["alu"]["achieved"])
+    for k, v in traffic["entries"].items():
+        print(k, v["hbm_bytes_per_launch"])
+
+
+if __name__ == "__main__":
+    main()
