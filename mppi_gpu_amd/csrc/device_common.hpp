@@ -19,7 +19,10 @@ namespace mppi {
 // 0xBB67AE85): per round two v_mad_u64_u32 (each yields the high AND the low product word) and
 // two v_bitop3_b32 with truth table 0x96 = a ^ b ^ c, a gfx950 instruction hipcc does not form
 // from `hi ^ ctr ^ key` by itself (it emits two v_xor_b32 each; rocRAND's ten_rounds compiles to
-// 6 VALU per round, this to 4).  The round keys are wave-uniform and stay in SGPRs.
+// 6 VALU per round, this to 4).  Measured (tools/ubench_issue): v_mad_u64_u32 issues in 6.3 SIMD
+// cycles and v_bitop3_b32 in 4.2 -- half rate, about what the two v_xor it replaces cost -- so a
+// round is ~21 cycles and a block with its Box-Muller ~320: that, not the instruction count, is
+// the floor of the noise pass.  The round keys are wave-uniform and stay in SGPRs.
 struct PhiloxAt {
     __device__ __forceinline__ static unsigned int xor3(unsigned int a, unsigned int b,
                                                         unsigned int c)

@@ -153,8 +153,6 @@ class ShardedPointMassModel:
             self.transport = "collective"
         self._validated = True
         self.validated = self.transport == "direct"
-        self.validated = None       # verdict of the "auto" check: True = direct reproduced the
-                                    # collective's bits on every rank, False = fell back
 
     def memcpy_set_data(self, x, u, goal, w):
         if not self._validated:

@@ -363,8 +363,9 @@ def test_closed_loop_sequence_matches_oracle_chain(gpu):
 @pytest.mark.parametrize("A,K,T", [(2, 10000, 200), (3, 3000, 50), (1, 700, 33), (3, 40000, 120)])
 def test_deferred_combine_rides_and_flushes_with_equal_bits(gpu, A, K, T):
     """Mode 0 (default): back-to-back mppi_solve_async calls carry the previous solve's combine in
-    the next rollout launch (rollout blocks wait on the agent-scope counter for the new controls);
-    get_act flushes it stand-alone.  Both are the same device function: a closed-loop chain of
+    the next rollout launch (rollout blocks poll the tagged 8-byte words {value, tag} the applying
+    combine blocks publish for the new controls: no fence, no counter); get_act flushes it
+    stand-alone.  Both are the same device function: a closed-loop chain of
     get_act calls and a chain of asynchronous solves must end in identical bits.  Against the
     eager mode (1024-thread combine, another summation order) the controls agree to rounding."""
     c = ol.make_case(A, K, T, seed=124)
