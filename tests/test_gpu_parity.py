@@ -403,6 +403,35 @@ def test_deferred_combine_rides_and_flushes_with_equal_bits(gpu, A, K, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("A,K,T,ngl", [(3, 3000, 200, 4), (3, 12000, 200, 0), (2, 2500, 200, 8), (1, 900, 48, 4)])
+def test_packed_kernel_rides_and_flushes_with_equal_bits(gpu, A, K, T, ngl):
+    """The packed rollout in pipeline mode 0: back-to-back solves carry the previous solve's combine
+    at the front of the packed grid (k_rollout_packed_ride); a chain of blocking get_act calls
+    flushes every combine on its own.  Same device functions: identical bits, in sampling mode."""
+    c = ol.make_case(A, 1, T, seed=131, u_scale=0.03)
+    n = 7
+
+    def chain(blocking):
+        with _model(gpu, A, K, T, c) as m:
+            if ngl:
+                m.set_packing(ngl)
+            m.set_seed(8)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            geo = m.geometry()
+            assert geo["packed"] and geo["tile_groups"] <= 2 * geo["grid"], geo   # short enough to ride
+            for _ in range(n):
+                m.get_act() if blocking else m.solve_async()
+            act = m.sync_act()
+            inf = m.get_inf(x=False, e=False)
+            return act, inf["u"], inf["cost"], inf["beta"], inf["nabla"]
+
+    ride, flush = chain(False), chain(True)
+    for a, b in zip(ride, flush):
+        assert np.array_equal(a, b), "riding and flushed combine must give equal bits"
+    assert np.all(np.isfinite(ride[1]))
+
+
+@pytest.mark.gpu
 def test_deferred_combine_interleaved_with_everything_else(gpu):
     """A pending combine must be flushed by every call that reads or changes what it touches:
     set_x between asynchronous solves (rides on), get_u / get_inf / set_params / set_tuning /
