@@ -50,6 +50,8 @@
 
 namespace mppi {
 
+constexpr int kPkRow = 65;     // float4 per row of the weighted-noise slots in LDS (64 lanes + 1 pad)
+
 template <int A>
 struct PackedLane {     // wave-uniform constants held in VGPRs (see LaneParams in the fused kernel)
     float sp[A], sv[A];         // state scales
@@ -80,8 +82,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBT] U, one float4 per block
     float4* uclds = ulds + NBT;                                  // [NBT] lambda*inv_s*U
-    float4* buf = uclds + NBT;                                   // [4][64*NQ] weighted noise sums
-    float* misc = reinterpret_cast<float*>(buf + 4 * 64 * NQ);   // [8]
+    float4* buf = uclds + NBT;                                   // [4][NQ][kRow] weighted noise sums
+    float* misc = reinterpret_cast<float*>(buf + 4 * NQ * kPkRow);   // [8]
     float* ctab = misc + 8;                                      // [4][TPW + 2] trajectory costs
 
     const int lane = threadIdx.x & 63;
@@ -144,9 +146,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     float Mw = INFINITY, Sw = 0.0f;          // this WAVE's running minimum and exp-sum
     bool first = true;                       // no tile with a valid trajectory folded yet
     bool staged = false;                     // controls are in LDS (block-uniform)
-    // this lane's slot q of the weighted noise sums is bw[q * 64]: layout [wave][q][lane], so that
-    // every wave-instruction reads / writes one contiguous 1 KiB row (no bank conflicts)
-    float4* const bw = buf + wave * 64 * NQ + lane;
+    // this lane's slot q of the weighted noise sums is bw[q * kPkRow]: layout [wave][q][lane], so
+    // that every wave-instruction of the tile loop reads / writes one contiguous 1 KiB row; rows are
+    // 65 float4 apart so that the final merge, which gathers one lane of MANY rows per instruction,
+    // does not find them all in one bank (rows 1 KiB apart: 16-way conflicts, 2.4 us per block)
+    float4* const bw = buf + wave * NQ * kPkRow + lane;
 
 #ifdef MPPI_TRACE
     int tile_no = 0;
@@ -478,7 +482,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
                     for (int b = 0; b < BPG; ++b) {
                         const int q = gi * BPG + b;
-                        bw[q * 64] = make_float4(wg * e[q * 4], wg * e[q * 4 + 1], wg * e[q * 4 + 2],
+                        bw[q * kPkRow] = make_float4(wg * e[q * 4], wg * e[q * 4 + 1], wg * e[q * 4 + 2],
                                                  wg * e[q * 4 + 3]);
                     }
                 }
@@ -489,8 +493,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
                     for (int b = 0; b < BPG; ++b) {
                         const int q = gi * BPG + b;
-                        const float4 o = bw[q * 64];
-                        bw[q * 64] = make_float4(fmaf(wg, e[q * 4], o.x), fmaf(wg, e[q * 4 + 1], o.y),
+                        const float4 o = bw[q * kPkRow];
+                        bw[q * kPkRow] = make_float4(fmaf(wg, e[q * 4], o.x), fmaf(wg, e[q * 4 + 1], o.y),
                                                  fmaf(wg, e[q * 4 + 2], o.z), fmaf(wg, e[q * 4 + 3], o.w));
                     }
                 }
@@ -501,8 +505,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
                     for (int b = 0; b < BPG; ++b) {
                         const int q = gi * BPG + b;
-                        const float4 o = bw[q * 64];
-                        bw[q * 64] = make_float4(fmaf(wg, e[q * 4], alpha * o.x), fmaf(wg, e[q * 4 + 1], alpha * o.y),
+                        const float4 o = bw[q * kPkRow];
+                        bw[q * kPkRow] = make_float4(fmaf(wg, e[q * 4], alpha * o.x), fmaf(wg, e[q * 4 + 1], alpha * o.y),
                                                  fmaf(wg, e[q * 4 + 2], alpha * o.z), fmaf(wg, e[q * 4 + 3], alpha * o.w));
                     }
                 }
@@ -526,6 +530,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         misc[4 + wave] = Sw;
     }
     __syncthreads();
+    MPPI_STAMP(12);
     {
         const float M = fminf(fminf(misc[0], misc[1]), fminf(misc[2], misc[3]));
         float rw[4];
@@ -541,7 +546,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * TA);
         const int wq = threadIdx.x & 3;
         const float rq = (wq == 0) ? rw[0] : (wq == 1) ? rw[1] : (wq == 2) ? rw[2] : rw[3];
-        const float4* srcw = buf + wq * 64 * NQ;
+        const float4* srcw = buf + wq * NQ * kPkRow;
         for (int m0 = 0; m0 < NBT; m0 += kRolloutThreads / 4) {
             const int m = m0 + (threadIdx.x >> 2);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -554,7 +559,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     for (int x = 0; x < 5; ++x) {
                         const int sl = (jj + x) * NGT + r;    // group slot of the wavefront
                         const int ln = sl / NG;
-                        v[x] = srcw[((sl - ln * NG) * BPG + b) * 64 + ln];
+                        v[x] = srcw[((sl - ln * NG) * BPG + b) * kPkRow + ln];
                     }
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
@@ -564,7 +569,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 for (; jj < TPW; ++jj) {
                     const int sl = jj * NGT + r;
                     const int ln = sl / NG;
-                    const float4 v4 = srcw[((sl - ln * NG) * BPG + b) * 64 + ln];
+                    const float4 v4 = srcw[((sl - ln * NG) * BPG + b) * kPkRow + ln];
                     acc.x += v4.x; acc.y += v4.y; acc.z += v4.z; acc.w += v4.w;
                 }
                 acc.x *= rq; acc.y *= rq; acc.z *= rq; acc.w *= rq;
@@ -624,7 +629,7 @@ k_rollout_packed_ride(const RolloutHot h, const DeferredCombine d)
 template <int A, int NG>
 size_t packed_lds_bytes_t(int NBT, int TPW)
 {
-    return (size_t)NBT * 2 * 16 + (size_t)4 * 64 * NG * Dim<A>::BPG * 16
+    return (size_t)NBT * 2 * 16 + (size_t)4 * kPkRow * NG * Dim<A>::BPG * 16
            + (size_t)(8 + 4 * (TPW + 2)) * sizeof(float);
 }
 

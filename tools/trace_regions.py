@@ -82,6 +82,10 @@ dur = (t[:, 9] - t[:, 0]).astype(np.float64)
 start = t[:, 0] - t[:, 0].min()
 print("block duration entry->all tiles: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f   (latest start %d)"
       % (dur.min(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max(), start.max()))
+if geo["packed"] and (t[:, 12] > 0).all():
+    print("  packed exit: wait for the block's slowest wave p50 %.0f p90 %.0f, merge + partial store p50 %.0f p90 %.0f"
+          % (np.median(t[:, 12] - t[:, 9]), np.percentile(t[:, 12] - t[:, 9], 90),
+             np.median(t[:, 10] - t[:, 12]), np.percentile(t[:, 10] - t[:, 12], 90)))
 idx = np.arange(len(dur))
 print("  by bid %% 8 (XCD):", " ".join("%.0f" % np.median(dur[idx % 8 == x]) for x in range(8)))
 half = len(dur) // 2
