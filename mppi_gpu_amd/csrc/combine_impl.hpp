@@ -9,14 +9,14 @@ namespace mppi {
 
 struct CombineSmem {     // LDS of one combine block; carve from static or dynamic shared memory
     float* r;            // [kMaxParts]
-    float* red;          // [(THREADS/64) * 4 * kCombineCols]
+    float* red;          // [THREADS]: (THREADS/64) waves x 64/kCombineCols row groups x kCombineCols
     float* scal;         // [2 * THREADS/64]
     int* flag;           // [1]
 };
 template <int THREADS>
 constexpr int combine_smem_floats()
 {
-    return kMaxParts + (THREADS / 64) * 4 * kCombineCols + 2 * (THREADS / 64) + 1;
+    return kMaxParts + THREADS + 2 * (THREADS / 64) + 1;
 }
 template <int THREADS>
 __device__ __forceinline__ CombineSmem carve_combine_smem(float* base)
@@ -24,7 +24,7 @@ __device__ __forceinline__ CombineSmem carve_combine_smem(float* base)
     CombineSmem s;
     s.r = base;
     s.red = s.r + kMaxParts;
-    s.scal = s.red + (THREADS / 64) * 4 * kCombineCols;
+    s.scal = s.red + THREADS;
     s.flag = reinterpret_cast<int*>(s.scal + 2 * (THREADS / 64));
     return s;
 }
@@ -33,9 +33,9 @@ __device__ __forceinline__ CombineSmem carve_combine_smem(float* base)
 // Combine: beta (src/point_mass.cu:273-322), nabla (:328-377), weighted update
 // (:384-480), action read-out and shift (:195-199, :805-824) in one launch.
 //
-// Grid = (ceil(TA/16) column blocks) x (RS row splits), 1024 threads.  Every block recomputes
+// Grid = (ceil(TA/kCombineCols) column blocks) x (RS row splits).  Every block recomputes
 // beta and nabla from the (<= kMaxParts) partial minima / exp-sums in a fixed order, then sums
-// ITS rows of the weighted-noise partials for ITS 16 columns, all row loads in flight, four
+// ITS rows of the weighted-noise partials for ITS kCombineCols columns, all row loads in flight, 64/kCombineCols
 // rows per wave-instruction.  With RS > 1 the splits meet through a per-column-block ticket: each
 // stores its 64 sums, releases at agent scope and takes a ticket; the block that draws the
 // last ticket acquires and adds the RS slabs IN SPLIT ORDER (so the result does not depend on
@@ -334,7 +334,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     }
 
     MPPI_CSTAMP(3);
-    // `mine`: this rank's finished sums for the block's 16 columns (threads 0..15 of the block
+    // `mine`: this rank's finished sums for the block's columns (threads 0..kCombineCols-1 of the block
     // that applies them); apply_blk is block-uniform
     float mine = tot;
     bool apply_blk = true;

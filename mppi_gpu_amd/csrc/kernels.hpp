@@ -224,7 +224,11 @@ struct DeferredCombine {
 
 constexpr int kRolloutThreads = 256;
 constexpr int kCombineThreads = 1024;
-constexpr int kCombineCols = 16;
+constexpr int kCombineCols = 8;    // columns of U per combine block: with 8 (eight rows per
+                                   // wave-instruction) 625 block partials fit ONE row split of the
+                                   // 256-thread combine, so the riding combine has no split meeting
+                                   // (a store -> poll hop): C2 13.8 -> 13.5 us per solve, the
+                                   // stand-alone combine 6.1 -> 5.3 us at C3
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
 constexpr int kMaxRanks = 64;     // rank partials one combine block can hold (LDS xv[][16])
