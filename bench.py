@@ -432,6 +432,10 @@ def main():
             extra["c3"] = {"workload": desc3, "ms_per_step": dt3 * 1e3, "value": K3 / dt3,
                            "unit": "rollouts/s", "steps": 400, "geometry": geo3,
                            "roofline": roofline_entry("c3", K3, T3, A3, geo3, riding3, k3, kn3, cm3)}
+            m3.set_noise_store(False)
+            dt3n, k3n, _, _ = timed_engine_run(m3, 30, 200)
+            extra["c3"]["noise_not_materialised"] = {"ms_per_step": dt3n * 1e3,
+                                                     "rollout_kernel_ms": round(k3n, 5)}
             m3.close()
     # ---- config 4's strong-scaling leg (K = 1e6 global) when run on several GPUs ---------------
     if N > 1 and not args.rehearse_one_gpu and args.workload != "c4":
