@@ -2,7 +2,7 @@
 inputs.  Floating point, so tolerances are stated here:
 
   strict kernel  (one lane per trajectory, sequential)   cost: BIT-EXACT, beta: exact
-  fused kernel   (C lanes per trajectory, scan + tree)   cost: rtol 2e-6
+  fused kernels  (lanes share a trajectory, scan + tree) cost: rtol 3e-6 (achieved <= 2.0e-6)
   both                                                   nabla: rtol 2e-6 (strict) / max(1e-4, 8 ulp(c)/lambda) (fused)
                                                          weights: rtol 2e-5 (strict) / max(1e-3, 16 ulp(c)/lambda) (fused)
                                                          U, action: max-norm rel 1e-5
@@ -91,8 +91,10 @@ def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGM
         assert np.array_equal(inf["cost"], ref["cost"]), f"{tag}: cost not bit-exact"
         assert np.float32(inf["beta"]) == ref["beta"], tag
     else:
-        np.testing.assert_allclose(inf["cost"], ref["cost"], rtol=2e-6, atol=0, err_msg=tag)
-        np.testing.assert_allclose(inf["beta"], ref["beta"], rtol=2e-6, err_msg=tag)
+        # (the worst of a million samples reaches 2.0e-6, profiles/parity_r02.json: 600 rounded
+        #  additions per path cost; the typical sample is at 4e-7)
+        np.testing.assert_allclose(inf["cost"], ref["cost"], rtol=3e-6, atol=0, err_msg=tag)
+        np.testing.assert_allclose(inf["beta"], ref["beta"], rtol=3e-6, err_msg=tag)
     # fused kernel: a weight moves by (cost difference)/lambda RELATIVE, i.e. by a few ulp(cost)/lambda
     ulp_c = float(np.spacing(np.float32(np.abs(ref["cost"]).max()))) / lam
     np.testing.assert_allclose(inf["nabla"], ref["nabla"],
