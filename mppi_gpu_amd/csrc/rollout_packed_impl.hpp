@@ -522,9 +522,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     MPPI_STAMP(9);
 
     // ---- the block's partial: the four waves' running sums meet here, once ------------------------
-    //      M = min M_w, r_w = exp(-(M_w - M)/lambda), S = sum r_w S_w, and thread m adds Philox block m
-    //      of the horizon over the 4 waves x TPW trajectories in fixed order (a wave that saw no
-    //      valid trajectory has r_w = 0 and is skipped: its slots were never written)
+    //      M = min M_w, r_w = exp(-(M_w - M)/lambda), S = sum r_w S_w, N = sum r_w N_w
     if (lane == 0) {
         misc[wave] = Mw;
         misc[4 + wave] = Sw;
@@ -540,46 +538,44 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             rw[w] = (misc[w] < INFINITY) ? expf(-inv_lambda * (misc[w] - M)) : 0.0f;
             S = fmaf(rw[w], misc[4 + w], S);
         }
-        // work item (m, w): Philox block m of the horizon, wave w: thread t takes w = t % 4 and
-        // m = t / 4 (+ 64 per sweep), adds that wave's TPW trajectories (all loads in flight), and
-        // the four waves of a column meet inside the quad (DPP, fixed order)
+        // thread m adds Philox block m of the horizon over the 4 waves x TPW trajectories, in that
+        // order, five trajectories of all four waves (20 loads) in flight at a time
         float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * TA);
-        const int wq = threadIdx.x & 3;
-        const float rq = (wq == 0) ? rw[0] : (wq == 1) ? rw[1] : (wq == 2) ? rw[2] : rw[3];
-        const float4* srcw = buf + wq * NQ * kPkRow;
-        for (int m0 = 0; m0 < NBT; m0 += kRolloutThreads / 4) {
-            const int m = m0 + (threadIdx.x >> 2);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < NBT && rq != 0.0f) {
-                const int r = m / BPG, b = m - r * BPG;      // group and block of the trajectory
-                int jj = 0;
-                for (; jj + 5 <= TPW; jj += 5) {
-                    float4 v[5];
+        for (int m = threadIdx.x; m < NBT; m += kRolloutThreads) {
+            const int r = m / BPG, b = m - r * BPG;          // group and block of the trajectory
+            float4 acc[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int jj = 0; jj < TPW; jj += 5) {
+                float4 v[4][5];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
-                        const int sl = (jj + x) * NGT + r;    // group slot of the wavefront
-                        const int ln = sl / NG;
-                        v[x] = srcw[((sl - ln * NG) * BPG + b) * kPkRow + ln];
+                        v[w][x] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (jj + x < TPW && rw[w] != 0.0f) {  // (block-uniform; a wave that saw
+                            const int sl = (jj + x) * NGT + r; //  nothing never wrote its slots)
+                            const int ln = sl / NG;
+                            v[w][x] = buf[(w * NQ + (sl - ln * NG) * BPG + b) * kPkRow + ln];
+                        }
                     }
+                }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
-                        acc.x += v[x].x; acc.y += v[x].y; acc.z += v[x].z; acc.w += v[x].w;
+                        acc[w].x += v[w][x].x; acc[w].y += v[w][x].y;
+                        acc[w].z += v[w][x].z; acc[w].w += v[w][x].w;
                     }
                 }
-                for (; jj < TPW; ++jj) {
-                    const int sl = jj * NGT + r;
-                    const int ln = sl / NG;
-                    const float4 v4 = srcw[((sl - ln * NG) * BPG + b) * kPkRow + ln];
-                    acc.x += v4.x; acc.y += v4.y; acc.z += v4.z; acc.w += v4.w;
-                }
-                acc.x *= rq; acc.y *= rq; acc.z *= rq; acc.w *= rq;
             }
-            // (w0 + w1) + (w2 + w3), every lane of the quad ends with the same bits
-            acc.x += dpp<kQuadXor1>(acc.x); acc.y += dpp<kQuadXor1>(acc.y);
-            acc.z += dpp<kQuadXor1>(acc.z); acc.w += dpp<kQuadXor1>(acc.w);
-            acc.x += dpp<kQuadXor2>(acc.x); acc.y += dpp<kQuadXor2>(acc.y);
-            acc.z += dpp<kQuadXor2>(acc.z); acc.w += dpp<kQuadXor2>(acc.w);
-            if (m < NBT && wq == 0) Nout[m] = acc;
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                tot.x = fmaf(rw[w], acc[w].x, tot.x); tot.y = fmaf(rw[w], acc[w].y, tot.y);
+                tot.z = fmaf(rw[w], acc[w].z, tot.z); tot.w = fmaf(rw[w], acc[w].w, tot.w);
+            }
+            Nout[m] = tot;
         }
         if (threadIdx.x == 0) {
             g.part_m[bid] = M;
