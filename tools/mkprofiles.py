@@ -83,9 +83,29 @@ def main():
                     os.path.join(DST, f"r02_{tag}_kernel_stats.csv"))
     for tag in ("c2", "c2e", "c3"):
         shutil.copy(os.path.join(SRC, "prof", f"r2_{tag}_pmc.txt"), os.path.join(DST, f"r02_{tag}_pmc_sq.txt"))
+    def refresh(roof, key):
+        # bench.py filled the counter-derived fields from the summaries committed BEFORE this run:
+        # put this run's own (same box, same call) in their place
+        if not roof or key not in alu["entries"]:
+            return
+        a, t = alu["entries"][key], traffic["entries"].get(key)
+        roof["kernel_ms_rocprof"] = a["kernel_ms_rocprof"]
+        roof["frac_rocprof"] = round(roof["algorithmic_bytes_per_launch"] / (a["kernel_ms_rocprof"] * 1e-3)
+                                     / 1e9 / roof["peak"], 4)
+        if "alu" in roof:
+            roof["alu"].update(a["alu"])
+        if t:
+            roof["traffic"] = t["hbm_bytes_per_launch"]
+
     for f in ("bench_c2", "bench_c3", "bench_c4shard", "bench_c4full", "bench_c1", "bench_c2_sharded_1rank"):
         line = open(os.path.join(SRC, "r2", f + ".json")).read().strip().splitlines()[-1]
-        json.dump(json.loads(line), open(os.path.join(DST, f"r02_{f}.json"), "w"), indent=1)
+        d = json.loads(line)
+        if f == "bench_c2":
+            refresh(d.get("roofline"), "c2:chunks=16:ride")
+            refresh(((d.get("extra") or {}).get("c3") or {}).get("roofline"), "c3:packed4:plain")
+        if f == "bench_c3":
+            refresh(d.get("roofline"), "c3:packed4:plain")
+        json.dump(d, open(os.path.join(DST, f"r02_{f}.json"), "w"), indent=1)
     for f in ("ubench_issue.txt", "ubench_noise.txt", "latency_probe.txt"):
         txt = [l for l in open(os.path.join(SRC, "r2", f)).read().splitlines() if "warning" not in l]
         open(os.path.join(DST, "r02_" + f), "w").write("\n".join(txt) + "\n")
