@@ -55,11 +55,13 @@ void mppi_destroy(mppi_engine* e);
 int mppi_set_data(mppi_engine* e, const float* x0, const float* u, const float* goal,
                   const float* w);
 
-/* PointMassModel::set_x(x), src/point_mass.cu:482-486 */
+/* PointMassModel::set_x(x), src/point_mass.cu:482-486.  Host-only here: the state travels by
+ * value with the arguments of the next rollout launch, so the call touches no GPU and solves that
+ * are already enqueued keep the state they were enqueued with. */
 int mppi_set_x(mppi_engine* e, const float* x0);
 
 /* PointMassModel::get_x(x): declared at include/point_mass.hpp:34, never defined in the
- * reference; defined here as the read-back of the current x0[S]. */
+ * reference; defined here as the current x0[S] (what the next solve will start from). */
 int mppi_get_x(mppi_engine* e, float* x0);
 
 /* PointMassModel::get_act(next_act), src/point_mass.cu:129-203: one full solve
