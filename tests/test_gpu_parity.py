@@ -177,6 +177,8 @@ PACKED_CASES = [
     (4, 130, 37, 10, 0),
     (4, 50, 400, 10, 1),       # 400 groups per trajectory: one trajectory per wavefront
     (3, 7, 512, 4, 0),         # 128 groups per trajectory: two per wavefront
+    (1, 9, 1024, 4, 0),        # 256 groups per trajectory = 64 lanes x 4: exactly one wavefront each
+    (2, 21, 10, 5, 0),         # 5 groups per trajectory = one lane each, 64 trajectories per wavefront
 ]
 
 
@@ -199,6 +201,41 @@ def test_packed_kernel_matches_oracle(gpu, A, K, T, ngl, max_blocks):
     _check_solve(act, inf, ref, cost_exact=False, tag=f"packed A{A} K{K} T{T} {geo}")
     cost, X = ol.rollout(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], want_X=True)
     assert np.array_equal(inf["x"], X), "state trace reads the packed layout"
+
+
+def test_packed_kernel_random_shapes_against_oracle(gpu):
+    """Seeded sweep of the packed kernel over random (A, groups per lane, T a whole number of
+    groups, K, persistent grid, lambda, goal, weights incl. zeros): every boundary pattern between
+    trajectories and lanes that the shapes above do not name."""
+    rng = np.random.default_rng(20261005)
+    NGS = {1: [4], 2: [5, 8], 3: [4], 4: [10]}
+    SGS = {1: 4, 2: 2, 3: 4, 4: 1}
+    done = 0
+    for trial in range(30):
+        A = int(rng.integers(1, 5))
+        ngl = int(rng.choice(NGS[A]))
+        # groups per trajectory (the engine's LDS budget bounds the horizon at T*A ~ 1000)
+        ngt = int(rng.integers(ngl, min(64 * ngl, 140, 1000 // (SGS[A] * A)) + 1))
+        T = ngt * SGS[A]
+        K = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1025, 2500]))
+        lam = float(rng.choice([0.5, 1.0, 2.0]))
+        c = ol.make_case(A, K, T, seed=3000 + trial, u_scale=float(rng.choice([0.0, 0.05, 0.5])))
+        c["goal"] = rng.standard_normal(2 * A).astype(np.float32)
+        c["w"] = (np.abs(rng.standard_normal(2 * A) * 5) * (rng.random(2 * A) > 0.2)).astype(np.float32)
+        ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=lam)
+        with _model(gpu, A, K, T, c, max_blocks=int(rng.choice([0, 1, 3]))) as m:
+            m.set_packing(ngl)
+            m.set_params(lam)
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf(x=False)
+            geo = m.geometry()
+        assert geo["packed"]
+        assert np.array_equal(inf["e"], c["E"])
+        _check_solve(act, inf, ref, cost_exact=False, lam=lam,
+                     tag=f"packed trial {trial} A{A} K{K} T{T} {geo}")
+        done += 1
+    assert done == 30
 
 
 def test_packed_kernel_general_goal_and_zero_weights(gpu):
