@@ -129,6 +129,33 @@ def cpu_baseline_controller(A, K, T, threads, budget_s):
     return K * n / t_tot, n
 
 
+def measured_hbm_peak(torch, n_bytes=1 << 30, reps=12):
+    """the peak a plain device copy reaches on THIS box, measured in-run with
+    torch events on torch's current stream (1 GiB read + 1 GiB written per copy, best of `reps`),
+    and the same for a pure write (fill), since the rollout launch only stores."""
+    src = torch.empty(n_bytes // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    best_c = best_f = 0.0
+    for _ in range(3):
+        dst.copy_(src); dst.zero_()
+    for _ in range(reps):
+        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record(); dst.copy_(src); b.record(); dst.zero_(); c.record()
+        c.synchronize()
+        best_c = max(best_c, 2 * n_bytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+        best_f = max(best_f, n_bytes / (b.elapsed_time(c) * 1e-3) / 1e9)
+    del src, dst
+    torch.cuda.empty_cache()
+    return {"copy_GBs": round(best_c, 1), "fill_GBs": round(best_f, 1),
+            "what": "torch device copy / zero-fill of 1 GiB, best of %d, bytes read + written" % reps}
+
+
+def quantiles(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return {"median": xs[n // 2], "p10": xs[n // 10], "p90": xs[(n * 9) // 10], "n": n}
+
+
 def committed_profile(name):
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -375,6 +402,12 @@ def main():
                             "rollout_frac": round(ab / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                             if r_ms > 0 else None}
     m.set_profiling(0)
+    if roof is not None and rank == 0 and not args.rehearse_one_gpu:
+        pk = measured_hbm_peak(torch)
+        roof["peak_measured"] = pk
+        if pk["copy_GBs"] > 0:
+            roof["frac_of_measured_copy_peak"] = round(roof["achieved"] / pk["copy_GBs"], 4)
+            roof["frac_of_measured_fill_peak"] = round(roof["achieved"] / pk["fill_GBs"], 4)
 
     # ---- the reference's timed unit: a blocking get_act (+ set_x: the closed loop) -----------
     latency = None
@@ -385,15 +418,28 @@ def main():
         for _ in range(20):
             eng.get_act()
         fence()
+        per_call = []
         tl = time.perf_counter()
         for _ in range(n_lat):
+            t1 = time.perf_counter()
             eng.get_act()
+            per_call.append(time.perf_counter() - t1)
         t_get = (time.perf_counter() - tl) / n_lat
         tl = time.perf_counter()
         for _ in range(n_lat):
             eng.get_act()
             m.set_x(x_now)
         t_loop = (time.perf_counter() - tl) / n_lat
+        # median-of->=100 statistic of the back-to-back mode: 100 batches of 20
+        # solves, each batch timed to its own wait
+        per_batch = []
+        step_b = m.solve_async if sharded is None else sharded.solve_async
+        for _ in range(100):
+            t1 = time.perf_counter()
+            for _ in range(20):
+                step_b()
+            m.sync_act()
+            per_batch.append((time.perf_counter() - t1) / 20)
         if dist is not None:
             tt = torch.tensor([t_get, t_loop], device="cpu" if args.rehearse_one_gpu else "cuda",
                               dtype=torch.float64)
@@ -402,6 +448,12 @@ def main():
         latency = {"blocking_get_act_ms": round(t_get * 1e3, 5),
                    "blocking_get_act_plus_set_x_ms": round(t_loop * 1e3, 5),
                    "rollouts_per_s_blocking": N * K / t_get, "calls": n_lat,
+                   "blocking_get_act_ms_quantiles": {k: (round(v * 1e3, 5) if k != "n" else v)
+                                                     for k, v in quantiles(per_call).items()},
+                   "back_to_back_ms_per_solve_quantiles": dict(
+                       {k: (round(v * 1e3, 5) if k != "n" else v)
+                        for k, v in quantiles(per_batch).items()},
+                       what="100 batches of 20 solve_async + one wait, per-solve time of each batch"),
                    "what": "PointMassModel.get_act() through the Python binding: launch, solve, "
                            "wait for the action in host memory (reference src/main.cu:329-332)"}
 

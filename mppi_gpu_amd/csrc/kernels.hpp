@@ -110,7 +110,13 @@ extern unsigned long long* g_mppi_trace_buf;     // [kMaxParts][16], engine.hip
 #define MPPI_TRACE_PTR(h) ((h).trace)
 #define MPPI_STAMP(i)                                                                    \
     do {                                                                                 \
-        if (h.trace && threadIdx.x == 0) h.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+        if (h.trace && threadIdx.x == 0) {                                               \
+            h.trace[(size_t)blockIdx.x * 16 + (i)] = wall_clock64();                     \
+            if ((i) == 0) {   /* where the block runs: HW_ID (SE/CU/SIMD/wave slot), XCC_ID */ \
+                h.trace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  \
+                h.trace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20); \
+            }                                                                            \
+        }                                                                                \
     } while (0)
 #else
 #define MPPI_STAMP(i) do { } while (0)

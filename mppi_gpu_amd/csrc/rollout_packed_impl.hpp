@@ -31,6 +31,7 @@
 #pragma once
 #include "device_common.hpp"
 #include "combine_impl.hpp"
+#include <type_traits>
 
 // experiment switches (tools/mkvariant.sh): defaults are the measured best
 #ifndef MPPI_PK_FENCES
@@ -41,6 +42,12 @@
 #endif
 #ifndef MPPI_PK_PRIO
 #define MPPI_PK_PRIO 2         // s_setprio of the latency-bound passes (the Philox pass runs at 0)
+#endif
+#ifndef MPPI_PK_RACC3
+#define MPPI_PK_RACC3 1        // three cost accumulators per axis (shorter dependent chains)
+#endif
+#ifndef MPPI_PK_NOMINAL
+#define MPPI_PK_NOMINAL 1      // lane start states = nominal trajectory (once per block) + response to the noise
 #endif
 #if MPPI_PK_FENCES
 #define MPPI_PK_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -142,6 +149,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         }
     }
     const unsigned long long blk_base = h.solve_idx * (unsigned long long)NBT;
+#if MPPI_PK_NOMINAL
+    float dps_nom[A], dvs_nom[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) { dps_nom[i] = 0.f; dvs_nom[i] = 0.f; }
+#endif
 
     float Mw = INFINITY, Sw = 0.0f;          // this WAVE's running minimum and exp-sum
     bool first = true;                       // no tile with a valid trajectory folded yet
@@ -229,6 +241,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #if MPPI_PK_PRIO
         __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
 #endif
+        const bool stage_now = !staged;
         if (!staged) {
             if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBT, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
@@ -236,117 +249,139 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         }
         MPPI_PK_STAMP(2);
 
-        // ---- pass 1b: zero-state response of the lane's range(s): V = dt*S1,
-        //      P = B0*S1 + dt^2*((n-1)*S1 - S2), S1 = sum a_j, S2 = sum j*a_j, a = u + e.
-        //      A lane with a boundary needs the sums of its head [0, split) and tail separately:
-        //      the running sums are snapshot after group `split` (wave-uniform test first). -----
-        float S1[A], S2[A], S1h[A], S2h[A];
+        // ---- pass 1b + scan: the scaled state every lane starts from.  Zero-state response of the
+        //      lane's range(s) to accelerations a: V = dt*S1, P = B0*S1 + dt^2*((n-1)*S1 - S2),
+        //      S1 = sum a_j, S2 = sum j*a_j.  A lane with a boundary needs the sums of its head
+        //      [0, split) and tail separately: the running sums are snapshot after group `split`
+        //      (wave-uniform test first).  Then a segmented affine scan over the wavefront:
+        //      (n, P, V) o (n', P', V') = (n + n', P + n'*dt*V + P', V + V'); a range that holds a
+        //      trajectory start (flag) absorbs nothing from its left.  The lane's head starts from
+        //      base + scale * (what the lanes before it contributed).
+        //      MODE 0: a = u + e, base = x0 moved freely to the lane's first step.
+        //      The response is LINEAR in a, so (MPPI_PK_NOMINAL) the part of the nominal controls is
+        //      the same for every trajectory: MODE 1 (a = u) runs once per block and gives the
+        //      nominal start states; MODE 2 (a = e, base = nominal) runs per tile -- one addition
+        //      and the LDS reads of u less per normal, and the scan carries small numbers only. ---
+        auto lane_start = [&](auto mode_tag, const float (&bp)[A], const float (&bv)[A],
+                              float (&dps)[A], float (&dvs)[A]) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            float S1[A], S2[A], S1h[A], S2h[A];
 #pragma unroll
-        for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; S1h[i] = 0.f; S2h[i] = 0.f; }
-        float4 unext[BPG];                      // controls of the NEXT group: loaded a group ahead
+            for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; S1h[i] = 0.f; S2h[i] = 0.f; }
+            float4 unext[BPG];                      // controls of the NEXT group: loaded a group ahead
+            if constexpr (MODE != 2) {
 #pragma unroll
-        for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbh + b];       // (group 0 is always head)
+                for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbh + b];   // (group 0 is always head)
+            }
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            // (group by group: without the scheduling fences hipcc hoists the LDS loads of all
-            //  groups to the top of the pass and holds them in registers)
-            MPPI_PK_FENCE();
+            for (int gi = 0; gi < NG; ++gi) {
+                // (group by group: without the scheduling fences hipcc hoists the LDS loads of all
+                //  groups to the top of the pass and holds them in registers)
+                MPPI_PK_FENCE();
+                float u[BPG * 4];
+                if constexpr (MODE != 2) {
 #if !MPPI_PK_PREFETCH
-            {
-                const int rbc = ((gi < split) ? rbh : rbt) + gi * BPG;
+                    {
+                        const int rbc = ((gi < split) ? rbh : rbt) + gi * BPG;
 #pragma unroll
-                for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbc + b];
-            }
+                        for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbc + b];
+                    }
 #endif
-            float u[BPG * 4];
 #pragma unroll
-            for (int b = 0; b < BPG; ++b) {
-                u[b * 4 + 0] = unext[b].x; u[b * 4 + 1] = unext[b].y;
-                u[b * 4 + 2] = unext[b].z; u[b * 4 + 3] = unext[b].w;
-            }
+                    for (int b = 0; b < BPG; ++b) {
+                        u[b * 4 + 0] = unext[b].x; u[b * 4 + 1] = unext[b].y;
+                        u[b * 4 + 2] = unext[b].z; u[b * 4 + 3] = unext[b].w;
+                    }
 #if MPPI_PK_PREFETCH
-            if (gi + 1 < NG) {
-                const int rbn = ((gi + 1 < split) ? rbh : rbt) + (gi + 1) * BPG;
+                    if (gi + 1 < NG) {
+                        const int rbn = ((gi + 1 < split) ? rbh : rbt) + (gi + 1) * BPG;
 #pragma unroll
-                for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbn + b];
-            }
+                        for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbn + b];
+                    }
 #endif
+                }
 #pragma unroll
-            for (int s = 0; s < SG; ++s) {
+                for (int s = 0; s < SG; ++s) {
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    const float a = u[s * A + i] + e[gi * BPG * 4 + s * A + i];
-                    S1[i] += a;
-                    S2[i] = fmaf((float)(gi * SG + s), a, S2[i]);
+                    for (int i = 0; i < A; ++i) {
+                        float a;
+                        if constexpr (MODE == 0) a = u[s * A + i] + e[gi * BPG * 4 + s * A + i];
+                        else if constexpr (MODE == 1) a = u[s * A + i];
+                        else a = e[gi * BPG * 4 + s * A + i];
+                        S1[i] += a;
+                        S2[i] = fmaf((float)(gi * SG + s), a, S2[i]);
+                    }
+                }
+                if (gi + 1 < NG && (split_mask & (1u << (gi + 1)))) {
+                    const bool here = tail_slot && split == gi + 1;
+#pragma unroll
+                    for (int i = 0; i < A; ++i) {
+                        S1h[i] = here ? S1[i] : S1h[i];
+                        S2h[i] = here ? S2[i] : S2h[i];
+                    }
                 }
             }
-            if (gi + 1 < NG && (split_mask & (1u << (gi + 1)))) {
-                const bool here = tail_slot && split == gi + 1;
+            float Pz[A], Vz[A];
 #pragma unroll
-                for (int i = 0; i < A; ++i) {
-                    S1h[i] = here ? S1[i] : S1h[i];
-                    S2h[i] = here ? S2[i] : S2h[i];
-                }
+            for (int i = 0; i < A; ++i) {
+                if (!tail_slot) { S1h[i] = S1[i]; S2h[i] = S2[i]; }
+                const float S1t = S1[i] - S1h[i];
+                const float S2t = (S2[i] - S2h[i]) - nh * S1t;      // steps counted from the boundary
+                const float S1o = tail_slot ? S1t : S1h[i];
+                const float S2o = tail_slot ? S2t : S2h[i];
+                const float no = tail_slot ? nt : nh;
+                Vz[i] = P.dt * S1o;
+                Pz[i] = fmaf(P.dt2, fmaf(no - 1.0f, S1o, -S2o), P.B0 * S1o);
             }
-        }
-        float Pz[A], Vz[A];
-#pragma unroll
-        for (int i = 0; i < A; ++i) {
-            if (!tail_slot) { S1h[i] = S1[i]; S2h[i] = S2[i]; }
-            const float S1t = S1[i] - S1h[i];
-            const float S2t = (S2[i] - S2h[i]) - nh * S1t;      // steps counted from the boundary
-            const float S1o = tail_slot ? S1t : S1h[i];
-            const float S2o = tail_slot ? S2t : S2h[i];
-            const float no = tail_slot ? nt : nh;
-            Vz[i] = P.dt * S1o;
-            Pz[i] = fmaf(P.dt2, fmaf(no - 1.0f, S1o, -S2o), P.B0 * S1o);
-        }
-
-        // ---- segmented affine scan over the wavefront: (n, P, V) o (n', P', V') =
-        //      (n + n', P + n'*dt*V + P', V + V'); a range that holds a trajectory start (flag)
-        //      absorbs nothing from its left. --------------------------------------------------
-        {
-            int nacc = n_out, flg = flag0;
-            const int cr = lane & 15;
+            {
+                int nacc = n_out, flg = flag0;
+                const int cr = lane & 15;
 #define MPPI_PK_COMBINE(COND, GETF, GETI)                                           \
-            {                                                                       \
-                const int nl = GETI(nacc);                                          \
-                const int fl = GETI(flg);                                           \
-                float Pl[A], Vl[A];                                                 \
-                _Pragma("unroll") for (int i = 0; i < A; ++i) {                     \
-                    Pl[i] = GETF(Pz[i]);                                            \
-                    Vl[i] = GETF(Vz[i]);                                            \
-                }                                                                   \
-                if ((COND) && flg == 0) {                                           \
-                    const float tau = (float)nacc * P.dt;                           \
+                {                                                                   \
+                    const int nl = GETI(nacc);                                      \
+                    const int fl = GETI(flg);                                       \
+                    float Pl[A], Vl[A];                                             \
                     _Pragma("unroll") for (int i = 0; i < A; ++i) {                 \
-                        Pz[i] = fmaf(tau, Vl[i], Pl[i]) + Pz[i];                    \
-                        Vz[i] = Vl[i] + Vz[i];                                      \
+                        Pl[i] = GETF(Pz[i]);                                        \
+                        Vl[i] = GETF(Vz[i]);                                        \
                     }                                                               \
-                    nacc += nl;                                                     \
-                    flg = fl;                                                       \
-                }                                                                   \
-            }
-            MPPI_PK_COMBINE(cr >= 1, dpp<MPPI_ROW_SHR(1)>, dppi<MPPI_ROW_SHR(1)>)
-            MPPI_PK_COMBINE(cr >= 2, dpp<MPPI_ROW_SHR(2)>, dppi<MPPI_ROW_SHR(2)>)
-            MPPI_PK_COMBINE(cr >= 4, dpp<MPPI_ROW_SHR(4)>, dppi<MPPI_ROW_SHR(4)>)
-            MPPI_PK_COMBINE(cr >= 8, dpp<MPPI_ROW_SHR(8)>, dppi<MPPI_ROW_SHR(8)>)
-            MPPI_PK_COMBINE((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
-            MPPI_PK_COMBINE((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
+                    if ((COND) && flg == 0) {                                       \
+                        const float tau = (float)nacc * P.dt;                       \
+                        _Pragma("unroll") for (int i = 0; i < A; ++i) {             \
+                            Pz[i] = fmaf(tau, Vl[i], Pl[i]) + Pz[i];                \
+                            Vz[i] = Vl[i] + Vz[i];                                  \
+                        }                                                           \
+                        nacc += nl;                                                 \
+                        flg = fl;                                                   \
+                    }                                                               \
+                }
+                MPPI_PK_COMBINE(cr >= 1, dpp<MPPI_ROW_SHR(1)>, dppi<MPPI_ROW_SHR(1)>)
+                MPPI_PK_COMBINE(cr >= 2, dpp<MPPI_ROW_SHR(2)>, dppi<MPPI_ROW_SHR(2)>)
+                MPPI_PK_COMBINE(cr >= 4, dpp<MPPI_ROW_SHR(4)>, dppi<MPPI_ROW_SHR(4)>)
+                MPPI_PK_COMBINE(cr >= 8, dpp<MPPI_ROW_SHR(8)>, dppi<MPPI_ROW_SHR(8)>)
+                MPPI_PK_COMBINE((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
+                MPPI_PK_COMBINE((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
 #undef MPPI_PK_COMBINE
-        }
-        MPPI_PK_STAMP(3);
-        // start state of the lane's head, scaled: x0 moved freely for the time since the start of
-        // its trajectory plus what the lanes before it contributed
-        float dps[A], dvs[A];
+            }
 #pragma unroll
-        for (int i = 0; i < A; ++i) {
-            float Pex = dpp<kWaveShr1>(Pz[i]);
-            float Vex = dpp<kWaveShr1>(Vz[i]);
-            if (starts0) { Pex = 0.f; Vex = 0.f; }
-            dps[i] = fmaf(P.sp[i], Pex, dps1[i]);
-            dvs[i] = fmaf(P.sv[i], Vex, dvs0[i]);
-        }
+            for (int i = 0; i < A; ++i) {
+                float Pex = dpp<kWaveShr1>(Pz[i]);
+                float Vex = dpp<kWaveShr1>(Vz[i]);
+                if (starts0) { Pex = 0.f; Vex = 0.f; }
+                dps[i] = fmaf(P.sp[i], Pex, bp[i]);
+                dvs[i] = fmaf(P.sv[i], Vex, bv[i]);
+            }
+        };
+        float dps[A], dvs[A];
+#if MPPI_PK_NOMINAL
+        if (stage_now)      // (block-uniform) the nominal trajectory's state at the lane's first step
+            lane_start(std::integral_constant<int, 1>(), dps1, dvs0, dps_nom, dvs_nom);
+        lane_start(std::integral_constant<int, 2>(), dps_nom, dvs_nom, dps, dvs);
+#else
+        lane_start(std::integral_constant<int, 0>(), dps1, dvs0, dps, dvs);
+#endif
+        MPPI_PK_STAMP(3);
+        float4 unext[BPG];
 
         // ---- pass 2: dynamics + stage cost on the scaled state (src/point_mass_gpu.cu:97-107,
         //      src/cost.cu:42-55).  One cost accumulator per axis; where a trajectory ends inside
@@ -356,6 +391,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         float cH = 0.0f;
 #pragma unroll
         for (int i = 0; i < A; ++i) racc[i] = 0.0f;
+#if MPPI_PK_RACC3
+        float raccu[A], raccv[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) { raccu[i] = 0.0f; raccv[i] = 0.0f; }
+#endif
         float4 cnext[BPG];
 #pragma unroll
         for (int b = 0; b < BPG; ++b) { unext[b] = ulds[rbh + b]; cnext[b] = uclds[rbh + b]; }
@@ -394,17 +434,32 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     if (has_cg) pn += P.cg[i];
                     dvs[i] = fmaf(P.k3[i], a, dvs[i]);
                     dps[i] = pn;
+#if MPPI_PK_RACC3
+                    raccu[i] = fmaf(uc[s * A + i], es[i], raccu[i]);
+                    racc[i] = fmaf(pn, pn, racc[i]);
+                    raccv[i] = fmaf(dvs[i], dvs[i], raccv[i]);
+#else
                     racc[i] = fmaf(uc[s * A + i], es[i], racc[i]);
                     racc[i] = fmaf(pn, pn, racc[i]);
                     racc[i] = fmaf(dvs[i], dvs[i], racc[i]);
+#endif
                 }
             }
             if (gi + 1 < NG && (split_mask & (1u << (gi + 1)))) {
                 const bool here = tail_slot && split == gi + 1;
                 float tot = 0.0f;
+#if MPPI_PK_RACC3
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    tot += fmaf(dps[i], dps[i], fmaf(dvs[i], dvs[i], racc[i] + (raccu[i] + raccv[i])));
+                    raccu[i] = here ? 0.0f : raccu[i];
+                    raccv[i] = here ? 0.0f : raccv[i];
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < A; ++i)
                     tot += fmaf(dps[i], dps[i], fmaf(dvs[i], dvs[i], racc[i]));
+#endif
                 cH = here ? tot : cH;
 #pragma unroll
                 for (int i = 0; i < A; ++i) {
@@ -420,6 +475,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 const float fc = fmaf(dps[i], dps[i], dvs[i] * dvs[i]);
+#if MPPI_PK_RACC3
+                racc[i] += raccu[i] + raccv[i];
+#endif
                 c_last += racc[i] + (term ? fc : 0.0f);
             }
         }

@@ -92,3 +92,20 @@ half = len(dur) // 2
 print("  first half %.0f  second half %.0f" % (np.median(dur[:half]), np.median(dur[half:])))
 order = np.argsort(dur)
 print("  slowest blocks:", order[-12:], " fastest:", order[:12])
+
+# ---- placement: blocks per CU (HW_ID of wave 0 at entry: CU_ID [11:8], SH_ID [12], SE_ID [15:13];
+#      XCC_ID [3:0] of register 20), and the Philox-pass time by the number of blocks sharing the CU
+hw = buf[:, 14].astype(np.int64)
+xcc = buf[:, 15].astype(np.int64) & 0xF
+cu = ((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF))
+if hw.any():
+    ids, cnt = np.unique(cu, return_counts=True)
+    print("placement: %d distinct CUs hold the %d blocks; blocks per CU histogram:" % (len(ids), len(cu)),
+          dict(zip(*np.unique(cnt, return_counts=True))))
+    per = dict(zip(ids, cnt))
+    share = np.array([per[x] for x in cu])
+    for s in sorted(set(share)):
+        sel = share == s
+        print("   %d block(s) on the CU: n=%d  pass1a median %.0f  entry->all tiles median %.0f max %.0f  start median %.0f"
+              % (s, sel.sum(), np.median(d[sel, 1]), np.median(dur[sel]), dur[sel].max(), np.median(start[sel])))
+    print("   blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
