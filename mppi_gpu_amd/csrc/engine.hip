@@ -93,6 +93,7 @@ struct mppi_engine {
     // tuning aids, read from the environment ONCE at mppi_create (never per launch)
     int tune_combine_splits = 0;            // MPPI_COMBINE_SPLITS: row splits of the combine, 0 = auto
     int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
+    long long resident_ride = 0;            // blocks of the riding kernel variant the chip holds at once
 
     // geometry
     int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
@@ -290,6 +291,19 @@ int ensure_geometry(mppi_engine_t* e)
         max_blocks = per_cu > 0 ? (packed ? 1 : 3) * per_cu * ncu : 2048;
         if (max_blocks > 3072) max_blocks = 3072;
     }
+    {   // what the chip holds AT ONCE of the riding variant of this kernel (its blocks wait for each
+        // other inside the launch): a combine rides only in a launch that fits it (enqueue_rollout)
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            ncu = prop.multiProcessorCount;
+        const bool in_kernel_sampling = !e->injected;
+        const int per_cu_ride = strict ? 0
+            : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need, true)
+                     : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need, true);
+        e->resident_ride = (long long)per_cu_ride * ncu;
+    }
     if (max_blocks > mppi::kMaxParts) max_blocks = mppi::kMaxParts;
     const int grid = (int)(ntb < max_blocks ? ntb : max_blocks);
 
@@ -411,6 +425,19 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
         a.pk_gps[i] = (float)(sp * gp);
         a.pk_gvs[i] = (float)(sv * gv);
         if (gv != 0.0) a.pk_has_cg = 1;
+        // the row-aligned kernel's scaled state: scales of |w|, signs kept aside
+        const double fp = wp != 0.0 ? sqrt(fabs(wp)) : ldexp(1.0, -60);
+        const double fv = wv != 0.0 ? sqrt(fabs(wv)) : ldexp(1.0, -60);
+        a.fs_sp[i] = (float)fp;
+        a.fs_sv[i] = (float)fv;
+        a.fs_k1[i] = (float)(fp * (double)e->dt / fv);
+        a.fs_k2[i] = (float)(fp * (double)e->B0);
+        a.fs_k3[i] = (float)(fv * (double)e->dt);
+        a.fs_cg[i] = (float)(fp * (double)e->dt * gv);
+        a.fs_gps[i] = (float)(fp * gp);
+        a.fs_gvs[i] = (float)(fv * gv);
+        a.fs_sgp[i] = wp < 0.0 ? -1.0f : 1.0f;
+        a.fs_sgv[i] = wv < 0.0 ? -1.0f : 1.0f;
     }
     a.dt = e->dt;
     a.B0 = e->B0;
@@ -572,7 +599,20 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         // same bits).
         const bool short_launch =
             (long long)e->n_tileblk <= (long long)e->tune_ride_max_tiles * e->grid;
-        if (!carry || e->strict || e->pending_stream != st || !short_launch) {
+        // ... and only where EVERY block of the riding launch (rollout + combine role) holds a slot
+        // at once, by the occupancy API of the riding kernel itself: the rollout blocks wait for
+        // the combine blocks inside the launch, and with all of them resident no dispatch order
+        // can leave a waited-for block without a slot
+        bool co_resident = false;
+        if (carry && short_launch && e->resident_ride > 0) {
+            mppi::CombineArgs probe;
+            memset(&probe, 0, sizeof probe);
+            probe.TA = e->TA;
+            probe.n_parts = e->grid;
+            probe.row_splits = e->tune_combine_splits;
+            co_resident = (long long)e->grid + mppi::combine_small_prepare(probe) <= e->resident_ride;
+        }
+        if (!carry || e->strict || e->pending_stream != st || !short_launch || !co_resident) {
             const hipStream_t was = e->pending_stream;
             if ((rc = flush_pending(e))) return rc;
             // a solve that moves to another stream must still see the controls of the last one

@@ -339,24 +339,24 @@ extern template hipError_t launch_fused_a<2>(int, bool, int, const RolloutArgs&,
 extern template hipError_t launch_fused_a<3>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
 extern template hipError_t launch_fused_a<4>(int, bool, int, const RolloutArgs&, const DeferredCombine&, hipStream_t, LaunchTiming);
 template <int A>
-int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds);
-extern template int fused_blocks_per_cu_a<1>(int, bool, size_t);
-extern template int fused_blocks_per_cu_a<2>(int, bool, size_t);
-extern template int fused_blocks_per_cu_a<3>(int, bool, size_t);
-extern template int fused_blocks_per_cu_a<4>(int, bool, size_t);
+int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds, bool ride);
+extern template int fused_blocks_per_cu_a<1>(int, bool, size_t, bool);
+extern template int fused_blocks_per_cu_a<2>(int, bool, size_t, bool);
+extern template int fused_blocks_per_cu_a<3>(int, bool, size_t, bool);
+extern template int fused_blocks_per_cu_a<4>(int, bool, size_t, bool);
 
 // ---- packed rollout (rollout_packed_impl.hpp, instantiated in rollout_packed_a{1,2,3,4}.hip) ----
 template <int A>
 hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
                            const DeferredCombine& d, hipStream_t st, LaunchTiming tm);
 template <int A>
-int packed_blocks_per_cu_a(int NG, bool sample, size_t lds);
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride);
 template <int A>
 size_t packed_lds_bytes_a(int NG, int NBT, int TPW);
 #define MPPI_PACKED_EXTERN(A_)                                                                       \
     extern template hipError_t launch_packed_a<A_>(int, bool, int, const RolloutArgs&,               \
                                                    const DeferredCombine&, hipStream_t, LaunchTiming); \
-    extern template int packed_blocks_per_cu_a<A_>(int, bool, size_t);                               \
+    extern template int packed_blocks_per_cu_a<A_>(int, bool, size_t, bool);                               \
     extern template size_t packed_lds_bytes_a<A_>(int, int, int);
 MPPI_PACKED_EXTERN(1)
 MPPI_PACKED_EXTERN(2)
@@ -388,13 +388,13 @@ size_t packed_lds_bytes(int A, int NG, int NBT, int TPW)
     }
 }
 
-int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds)
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride)
 {
     switch (A) {
-        case 1: return packed_blocks_per_cu_a<1>(NG, sample, lds);
-        case 2: return packed_blocks_per_cu_a<2>(NG, sample, lds);
-        case 3: return packed_blocks_per_cu_a<3>(NG, sample, lds);
-        case 4: return packed_blocks_per_cu_a<4>(NG, sample, lds);
+        case 1: return packed_blocks_per_cu_a<1>(NG, sample, lds, ride);
+        case 2: return packed_blocks_per_cu_a<2>(NG, sample, lds, ride);
+        case 3: return packed_blocks_per_cu_a<3>(NG, sample, lds, ride);
+        case 4: return packed_blocks_per_cu_a<4>(NG, sample, lds, ride);
         default: return 0;
     }
 }
@@ -411,13 +411,13 @@ hipError_t launch_rollout_packed(int A, int NG, bool sample, int grid, const Rol
     }
 }
 
-int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds)
+int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds, bool ride)
 {
     switch (A) {
-        case 1: return fused_blocks_per_cu_a<1>(NGt, sample, lds);
-        case 2: return fused_blocks_per_cu_a<2>(NGt, sample, lds);
-        case 3: return fused_blocks_per_cu_a<3>(NGt, sample, lds);
-        case 4: return fused_blocks_per_cu_a<4>(NGt, sample, lds);
+        case 1: return fused_blocks_per_cu_a<1>(NGt, sample, lds, ride);
+        case 2: return fused_blocks_per_cu_a<2>(NGt, sample, lds, ride);
+        case 3: return fused_blocks_per_cu_a<3>(NGt, sample, lds, ride);
+        case 4: return fused_blocks_per_cu_a<4>(NGt, sample, lds, ride);
         default: return 0;
     }
 }
@@ -448,7 +448,7 @@ hipError_t probe_code_object(int A)
     }
     if (rc != hipSuccess) return rc;
     // the fused rollout lives in its own translation unit: the occupancy query resolves its symbol
-    return rollout_blocks_per_cu(A, 1, true, rollout_lds_bytes(8, 16)) > 0 ? hipSuccess
+    return rollout_blocks_per_cu(A, 1, true, rollout_lds_bytes(8, 16), false) > 0 ? hipSuccess
                                                                              : hipErrorInvalidDeviceFunction;
 }
 

@@ -75,6 +75,10 @@ struct RolloutArgs {
     // d_v' = d_v + k3 a, stage cost d_p'^2 + d_v'^2; computed on the host in double precision
     float pk_sp[4], pk_sv[4], pk_k1[4], pk_k2[4], pk_k3[4], pk_cg[4], pk_gps[4], pk_gvs[4];
     int pk_has_cg;         // some velocity goal != 0
+    // row-aligned kernel, same scaled dynamics for weights of EITHER sign: the scales are taken of
+    // |w| and the stage-cost terms of an axis enter with sign(w), applied once per chunk
+    float fs_sp[4], fs_sv[4], fs_k1[4], fs_k2[4], fs_k3[4], fs_cg[4], fs_gps[4], fs_gvs[4];
+    float fs_sgp[4], fs_sgv[4];
     int store_e;           // 0: the sampled noise is not written to Eint (mppi_set_noise_store);
                            // it is a pure function of (seed, solve, sample, step) and is
                            // regenerated on request (launch_regen_noise)
@@ -262,7 +266,7 @@ struct ELayout {
 // (0-terminated), its LDS need and its launcher; grid = rollout blocks, d as for the fused kernel.
 const int* packed_ng_list(int A);
 size_t packed_lds_bytes(int A, int NG, int NBTp, int TPW);
-int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds);
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride = false);
 hipError_t launch_rollout_packed(int A, int NG, bool sample, int grid, const RolloutArgs& a,
                                  const DeferredCombine& d, hipStream_t st,
                                  LaunchTiming tm = LaunchTiming());
@@ -274,7 +278,8 @@ int rollout_group_blocks(int A);
 int rollout_max_groups(int A);
 int rollout_pick_ng_template(int A, int ng);
 size_t rollout_lds_bytes(int NBTp, int TAp);
-int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds);   // occupancy API, 0 = unknown
+int rollout_blocks_per_cu(int A, int NGt, bool sample, size_t lds, bool ride = false);   // occupancy API, 0 = unknown;
+                                                 // ride: of the riding variant (blocks that wait for each other)
 // hipSuccess iff the code object of this library loads on the current device and holds the kernels
 // an engine of this act_dim launches (asked through hipFuncGetAttributes: an error code here,
 // where the first launch would abort inside the runtime)

@@ -5,6 +5,9 @@
 #include "device_common.hpp"
 #include "combine_impl.hpp"
 
+#ifndef MPPI_FUSED_SCALED
+#define MPPI_FUSED_SCALED 1    // pass 2 on the scaled state (7 instead of 11 VALU per normal)
+#endif
 #ifndef MPPI_FUSED_PRIO
 #define MPPI_FUSED_PRIO 2      // s_setprio of the passes after the Philox pass (which runs at 0)
 #endif
@@ -27,8 +30,12 @@ namespace mppi {
 // ------------------------------------------------------------------------------------------
 template <int A>
 struct LaneParams {     // wave-uniform problem constants, deliberately held in VGPRs: kept in
-    float goal[2 * A];  // SGPRs they and the launch geometry exceed the 102-SGPR file, and
-    float w[2 * A];     // every spilled scalar costs a v_readlane + s_nop in the hot loop
+#if MPPI_FUSED_SCALED   // SGPRs they and the launch geometry exceed the 102-SGPR file, and
+    float k1[A], k2[A], k3[A], cg[A];   // every spilled scalar costs a v_readlane + s_nop in
+#else                                   // the hot loop
+    float goal[2 * A];
+    float w[2 * A];
+#endif
     float sigma[A];
     float dt, B0, dt2;
 };
@@ -95,8 +102,17 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
     if constexpr (!deferred) stage_controls_lds();
     LaneParams<A> P;
     float x0p[A], x0v[A];
+#if MPPI_FUSED_SCALED
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        P.k1[i] = to_vgpr(g.fs_k1[i]); P.k2[i] = to_vgpr(g.fs_k2[i]);
+        P.k3[i] = to_vgpr(g.fs_k3[i]); P.cg[i] = to_vgpr(g.fs_cg[i]);
+    }
+    const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
+#else
 #pragma unroll
     for (int i = 0; i < 2 * A; ++i) { P.goal[i] = to_vgpr(g.goal[i]); P.w[i] = to_vgpr(g.w[i]); }
+#endif
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         P.sigma[i] = to_vgpr(g.sigma[i]);
@@ -290,6 +306,93 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
             }
         }
 
+#if MPPI_FUSED_SCALED
+        // ---- pass 2: dynamics + stage cost over the own chunk (src/point_mass_gpu.cu:97-107,
+        //      src/cost.cu:42-55) on the SCALED state d_p = sqrt|w_p| (p - g_p),
+        //      d_v = sqrt|w_v| (v - g_v): d_p' = d_p + k1 d_v + k2 a (+ cg), d_v' = d_v + k3 a, and
+        //      the state part of the stage cost is sgn(w_p) d_p'^2 + sgn(w_v) d_v'^2 -- 7 VALU per
+        //      normal instead of 11 (gains from the host in double; a zero weight gets the scale
+        //      2^-60).  One accumulator per axis and term; the signs are applied when they are
+        //      summed.  No per-step masking: the chunk that holds step T-1 takes a snapshot (cost
+        //      so far, state) at the wave-uniform step n_last and uses that. -----------------------
+        float cpart = 0.0f;
+        {
+            float dps[A], dvs[A], ru[A], rp[A], rv[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                dps[i] = fmaf(g.fs_sp[i], p[i], -g.fs_gps[i]);
+                dvs[i] = fmaf(g.fs_sv[i], v[i], -g.fs_gvs[i]);
+                ru[i] = 0.0f; rp[i] = 0.0f; rv[i] = 0.0f;
+            }
+            auto signed_total = [&]() {
+                float t = 0.0f;
+#pragma unroll
+                for (int i = 0; i < A; ++i) t += ru[i];
+#pragma unroll
+                for (int i = 0; i < A; ++i) t = fmaf(g.fs_sgp[i], rp[i], t);
+#pragma unroll
+                for (int i = 0; i < A; ++i) t = fmaf(g.fs_sgv[i], rv[i], t);
+                return t;
+            };
+            if constexpr (!EXACT) asm volatile("" : "+s"(ngs));
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                if (gi < ngs) {
+                    float u[BPG * 4], uc[BPG * 4];
+#pragma unroll
+                    for (int j = 0; j < BPG; ++j) {
+                        const float4 u4 = ulds[c * nq + gi * BPG + j];
+                        const float4 c4 = uclds[c * nq + gi * BPG + j];
+                        u[j * 4 + 0] = u4.x; u[j * 4 + 1] = u4.y; u[j * 4 + 2] = u4.z; u[j * 4 + 3] = u4.w;
+                        uc[j * 4 + 0] = c4.x; uc[j * 4 + 1] = c4.y; uc[j * 4 + 2] = c4.z; uc[j * 4 + 3] = c4.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < SG; ++s) {
+                        const int sl = gi * SG + s;
+                        const float* es = &e[gi * BPG * 4 + s * A];
+#pragma unroll
+                        for (int i = 0; i < A; ++i) {
+                            const float a = u[s * A + i] + es[i];
+                            float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
+                            if (has_cg) pn += P.cg[i];
+                            dvs[i] = fmaf(P.k3[i], a, dvs[i]);
+                            dps[i] = pn;
+                            ru[i] = fmaf(uc[s * A + i], es[i], ru[i]);
+                            rp[i] = fmaf(pn, pn, rp[i]);
+                            rv[i] = fmaf(dvs[i], dvs[i], rv[i]);
+                        }
+                        if (sl + 1 == n_last) {
+                            // wave-uniform scalar branch, taken at one step per tile: the snapshot
+                            // goes through the thread's LDS slot (kept in registers it becomes
+                            // loop-carried values that hipcc copies at EVERY step)
+                            snap[0] = signed_total();
+#pragma unroll
+                            for (int i = 0; i < A; ++i) {
+                                snap[(1 + i) * kRolloutThreads] = dps[i];
+                                snap[(1 + A + i) * kRolloutThreads] = dvs[i];
+                            }
+                        }
+                    }
+                }
+            }
+            cpart = signed_total();
+        }
+        {
+            const float cT = snap[0];
+            float fc = 0.0f;    // Cost::final_cost (src/cost.cu:57-64) on the state after step T-1
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float d = snap[(1 + i) * kRolloutThreads];
+                fc = fmaf(g.fs_sgp[i] * d, d, fc);
+            }
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                const float d = snap[(1 + A + i) * kRolloutThreads];
+                fc = fmaf(g.fs_sgv[i] * d, d, fc);
+            }
+            cpart = (c < c_last) ? cpart : (c == c_last ? cT + fc : 0.0f);
+        }
+#else
         // ---- pass 2: dynamics + stage cost over the own chunk (src/point_mass_gpu.cu:97-107,
         //      src/cost.cu:42-55).  No per-step masking: the chunk that holds step T-1 takes a
         //      snapshot (cost so far, state) at the wave-uniform step n_last and uses that. ----
@@ -366,6 +469,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
             }
             cpart = (c < c_last) ? cpart : (c == c_last ? cT + fc : 0.0f);
         }
+#endif
         if (first) MPPI_STAMP(4);
         const float cost = group_sum<LOGC>(cpart);
         if (valid && c == 0) cost_out[kloc] = cost;
@@ -505,39 +609,59 @@ hipError_t launch_fused_t(bool sample, int grid, const RolloutArgs& a, const Def
     return hipGetLastError();
 }
 
-// resident blocks per CU of the instantiation (occupancy API; used only to size the persistent
-// grid, never for correctness)
+// resident blocks per CU of the instantiation (occupancy API).  ride = false: the plain kernel, used
+// only to size the persistent grid; ride = true: the riding variants, whose blocks WAIT for each
+// other inside the launch -- the engine lets a combine ride only in a launch whose blocks all fit
+// the chip at once by this number.
 template <int A, int NG>
-int fused_blocks_per_cu_t(bool sample, size_t lds)
+int fused_blocks_per_cu_t(bool sample, size_t lds, bool ride)
 {
     int n = 0;
-    hipError_t rc = sample
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, true>,
-                                                       kRolloutThreads, lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, false>,
-                                                       kRolloutThreads, lds);
-    return rc == hipSuccess ? n : 0;
+    hipError_t rc;
+    if (!ride) {
+        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, true>,
+                                                                   kRolloutThreads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_fused<A, NG, false>,
+                                                                   kRolloutThreads, lds);
+        return rc == hipSuccess ? n : 0;
+    }
+    if (lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
+    rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_ride<A, NG, true>,
+                                                               kRolloutThreads, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_ride<A, NG, false>,
+                                                               kRolloutThreads, lds);
+    if (rc != hipSuccess) return 0;
+    if constexpr (kExactGroupsPays<A>) {
+        int m = 0;
+        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_rollout_ride<A, NG, true, true>,
+                                                                   kRolloutThreads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_rollout_ride<A, NG, false, true>,
+                                                                   kRolloutThreads, lds);
+        if (rc != hipSuccess) return 0;
+        if (m < n) n = m;
+    }
+    return n;
 }
 
 template <int A>
-int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds)
+int fused_blocks_per_cu_a(int NGt, bool sample, size_t lds, bool ride)
 {
     if constexpr (A == 3) {
         switch (NGt) {
-            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds);
-            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds);
-            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds);
-            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds);
+            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds, ride);
+            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds, ride);
+            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds, ride);
+            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds, ride);
             default: return 0;
         }
     } else {
         switch (NGt) {
-            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds);
-            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds);
-            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds);
-            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds);
-            case 13: return fused_blocks_per_cu_t<A, 13>(sample, lds);
-            case 20: return fused_blocks_per_cu_t<A, 20>(sample, lds);
+            case 1: return fused_blocks_per_cu_t<A, 1>(sample, lds, ride);
+            case 2: return fused_blocks_per_cu_t<A, 2>(sample, lds, ride);
+            case 4: return fused_blocks_per_cu_t<A, 4>(sample, lds, ride);
+            case 7: return fused_blocks_per_cu_t<A, 7>(sample, lds, ride);
+            case 13: return fused_blocks_per_cu_t<A, 13>(sample, lds, ride);
+            case 20: return fused_blocks_per_cu_t<A, 20>(sample, lds, ride);
             default: return 0;
         }
     }

@@ -705,15 +705,23 @@ hipError_t launch_packed_t(bool sample, int grid, const RolloutArgs& a, const De
     return hipGetLastError();
 }
 
-template <int A, int NG>
-int packed_blocks_per_cu_t(bool sample, size_t lds)
+template <int A, int NG>      // ride: the riding variant (see fused_blocks_per_cu_t)
+int packed_blocks_per_cu_t(bool sample, size_t lds, bool ride)
 {
     int n = 0;
-    hipError_t rc = sample
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, true>,
-                                                       kRolloutThreads, lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, false>,
-                                                       kRolloutThreads, lds);
+    hipError_t rc;
+    if (ride) {
+        if (lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
+        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed_ride<A, NG, true>,
+                                                                   kRolloutThreads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed_ride<A, NG, false>,
+                                                                   kRolloutThreads, lds);
+    } else {
+        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, true>,
+                                                                   kRolloutThreads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, false>,
+                                                                   kRolloutThreads, lds);
+    }
     return rc == hipSuccess ? n : 0;
 }
 
@@ -742,17 +750,17 @@ hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
 }
 
 template <int A>
-int packed_blocks_per_cu_a(int NG, bool sample, size_t lds)
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride)
 {
     if constexpr (A == 1) {
-        if (NG == 4) return packed_blocks_per_cu_t<1, 4>(sample, lds);
+        if (NG == 4) return packed_blocks_per_cu_t<1, 4>(sample, lds, ride);
     } else if constexpr (A == 2) {
-        if (NG == 5) return packed_blocks_per_cu_t<2, 5>(sample, lds);
-        if (NG == 8) return packed_blocks_per_cu_t<2, 8>(sample, lds);
+        if (NG == 5) return packed_blocks_per_cu_t<2, 5>(sample, lds, ride);
+        if (NG == 8) return packed_blocks_per_cu_t<2, 8>(sample, lds, ride);
     } else if constexpr (A == 3) {
-        if (NG == 4) return packed_blocks_per_cu_t<3, 4>(sample, lds);
+        if (NG == 4) return packed_blocks_per_cu_t<3, 4>(sample, lds, ride);
     } else {
-        if (NG == 10) return packed_blocks_per_cu_t<4, 10>(sample, lds);
+        if (NG == 10) return packed_blocks_per_cu_t<4, 10>(sample, lds, ride);
     }
     return 0;
 }

@@ -255,6 +255,17 @@ def test_packed_kernel_general_goal_and_zero_weights(gpu):
         inf = m.get_inf(x=False, e=False)
         assert m.geometry()["packed"]
     _check_solve(act, inf, ref, cost_exact=False, tag="packed goal/zero-w", lam=lam)
+    # the row-aligned kernel runs the same scaled dynamics (signs of the weights kept aside)
+    for chunks in (0, 4, 64):
+        with _model(gpu, A, K, T, c) as m:
+            m.set_packing(-1)
+            m.set_tuning(chunks=chunks)
+            m.set_params(lam, inv_s=inv_s)
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf(x=False, e=False)
+            assert not m.geometry()["packed"]
+        _check_solve(act, inf, ref, cost_exact=False, tag=f"row-aligned goal/zero-w chunks={chunks}", lam=lam)
     # negative weights are not a cost the scaled form can carry: the row-aligned kernel takes over
     c["w"] = np.array([2, -1, 1, 5, 3, 0], np.float32)
     ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"])

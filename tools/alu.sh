@@ -1,14 +1,15 @@
 #!/bin/bash
 # usage: tools/alu.sh <tag> <bench args...>
 # VALU side of the roofline: instruction counts by class and VALU-busy time of every mppi kernel
-# (two SQ counter passes with --kernel-trace only), summary -> gpurun_out/prof/<tag>_alu.json:
+# (two SQ counter passes and one GRBM pass, --kernel-trace only), summary -> gpurun_out/prof/<tag>_alu.json:
 # per kernel the mean per-dispatch counter totals and the mean dispatch duration of the same runs.
 tag=$1; shift
 mkdir -p gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT" \
-           "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU"; do
+           "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU" \
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/prof/${tag}_alu$i -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-events "$@" > gpurun_out/prof/${tag}_alu$i.log 2>&1 || { tail -3 gpurun_out/prof/${tag}_alu$i.log; exit 1; }
 done
@@ -36,3 +37,4 @@ json.dump({"args": sys.argv[2:], "kernels": out}, open(f'gpurun_out/prof/{tag}_a
 for k, e in out.items():
     print(k[:70], {c: round(v, 1) for c, v in e.items()})
 PY
+rm -rf gpurun_out/prof/${tag}_alu1 gpurun_out/prof/${tag}_alu2 gpurun_out/prof/${tag}_alu3

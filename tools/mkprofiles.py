@@ -67,6 +67,20 @@ def main():
             cyc = (n64 * COST["INT64"] + ntr * COST["TRANS_F32"] + nb3 * COST["BITOP3"]
                    + (n_all - n64 - ntr - nb3) * COST["OTHER"])
             simd_cycles = N_SIMD * us * 1e-6 * F_NOMINAL
+            # counter-based: rocprof's VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE
+            # (SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE is reported per XCD instance
+            # or summed over the 8 of them: normalised by what the dispatch duration implies)
+            busy = None
+            gui = v.get("GRBM_GUI_ACTIVE")
+            act = v.get("SQ_ACTIVE_INST_VALU")
+            dur_p = v.get("dispatch_us_mean_in_these_passes") or us
+            if gui and act:
+                inst = 8.0 if gui / (dur_p * 1e-6) > 6e9 else 1.0
+                gui_cycles = gui / inst
+                busy = {"valu_busy": round(act * 4.0 / N_SIMD / gui_cycles, 4),
+                        "gpu_clock_GHz_in_profiled_pass": round(gui_cycles / (dur_p * 1e-6) / 1e9, 3),
+                        "SQ_ACTIVE_INST_VALU": round(act), "GRBM_GUI_ACTIVE_per_xcd": round(gui_cycles),
+                        "formula": "SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / GRBM_GUI_ACTIVE (rocprof VALUBusy)"}
             alu["entries"][key] = {
                 "kernel": name, "kernel_ms_rocprof": round(us * 1e-3, 6), "rocprof_calls": calls,
                 "alu": {"bound": "valu", "achieved": round(cyc / simd_cycles, 4), "peak": 1.0,
@@ -75,7 +89,8 @@ def main():
                         "v_mad_u64_u32": round(n64), "transcendental": round(ntr),
                         "fma_f32": round(v["SQ_INSTS_VALU_FMA_F32"]), "add_f32": round(v["SQ_INSTS_VALU_ADD_F32"]),
                         "mul_f32": round(v["SQ_INSTS_VALU_MUL_F32"]),
-                        "issue_cycles_model": round(cyc)}}
+                        "issue_cycles_model": round(cyc),
+                        "counter": busy}}
     json.dump(traffic, open(os.path.join(DST, "traffic_r02.json"), "w"), indent=1)
     json.dump(alu, open(os.path.join(DST, "alu_r02.json"), "w"), indent=1)
     for tag in ("c2", "c2e", "c3", "c4"):

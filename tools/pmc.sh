@@ -23,3 +23,4 @@ with open(f'gpurun_out/prof/{tag}_pmc.txt','w') as out:
         line=k[:60]+' waves=%d'%w+' | per-wave: '+' '.join('%s=%.0f'%(c.replace('SQ_',''),sum(v)/len(v)/w) for c,v in sorted(d.items()) if c!='SQ_WAVES')
         print(line); out.write(line+'\n')
 PY
+rm -rf gpurun_out/prof/${tag}_p1 gpurun_out/prof/${tag}_p2

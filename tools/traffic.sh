@@ -28,3 +28,4 @@ for k,d in out.items():
 json.dump({"args":sys.argv[2:],"kernels":res},open(f'gpurun_out/prof/{tag}_traffic.json','w'),indent=1)
 print(json.dumps(res,indent=1))
 PY
+rm -rf gpurun_out/prof/${tag}_FETCH_SIZE gpurun_out/prof/${tag}_WRITE_SIZE

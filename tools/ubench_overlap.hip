@@ -1,6 +1,7 @@
 // Do consecutive launches overlap?  Each launch spins ~10 us and stamps the wall clock at the start
 // of its first block and at the end of its last; printed: start(j+1) - end(j) in us for (a) one
-// stream, ordinary launches, (b) one stream, hipExtAnyOrderLaunch, (c) two streams in turn.
+// stream, ordinary launches, (b) one stream, hipExtAnyOrderLaunch, (c) two streams in turn,
+// (d) one stream, hipLaunchCooperativeKernel.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdio>
@@ -29,13 +30,18 @@ int main(int argc, char** argv)
     hipEvent_t ea, eb; hipEventCreate(&ea); hipEventCreate(&eb);
     std::vector<unsigned long long> h(n * 2);
     double host_us = 0;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipDeviceSynchronize();
             auto t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < n; ++i) {
                 hipStream_t st = (mode == 2) ? s[i & 1] : s[0];
-                if (mode == 1)
+                if (mode == 3) {       // cooperative launch: all blocks guaranteed co-resident
+                    unsigned long long* dd = d; int slot = i; unsigned long long tk = ticks;
+                    void* args[] = {&dd, &slot, &tk};
+                    hipLaunchCooperativeKernel(reinterpret_cast<void*>(k_spin), dim3(grid), dim3(256),
+                                               args, 0, st);
+                } else if (mode == 1)
                     hipExtLaunchKernelGGL(k_spin, dim3(grid), dim3(256), 0, st, nullptr, nullptr,
                                           hipExtAnyOrderLaunch, d, i, ticks);
                 else
@@ -59,7 +65,7 @@ int main(int argc, char** argv)
         }
         std::sort(gap.begin(), gap.end()); std::sort(per.begin(), per.end());
         printf("mode %d (%s): start(j+1)-end(j) median %.2f us (p10 %.2f p90 %.2f), period median %.2f us; host enqueue %.2f us per launch\n",
-               mode, mode == 0 ? "one stream" : mode == 1 ? "one stream, any-order flag" : "two streams in turn",
+               mode, mode == 0 ? "one stream" : mode == 1 ? "one stream, any-order flag" : mode == 2 ? "two streams in turn" : "one stream, cooperative launch",
                gap[gap.size() / 2], gap[gap.size() / 10], gap[gap.size() * 9 / 10], per[per.size() / 2], host_us);
     }
     return 0;
