@@ -255,61 +255,80 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     // ---- every global load this block needs is issued up front: the partial minima and
     //      exp-sums, the first batch of weighted-noise rows and the nominal control; beta,
     //      nabla and the rescale factors are computed while they are in flight -------------
-    float mreg[PT], sreg[PT];
-    const int jmax = (a.n_parts + THREADS - 1) / THREADS;   // sweeps that hold any partial at all
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int p = tid + j * THREADS;
-        mreg[j] = INFINITY;
-        sreg[j] = 0.0f;
-        if (j < jmax) {                                      // block-uniform
-            mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
-            sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
-        }
-    }
+    // (measured and dropped: every WAVE working out beta, nabla and all rescale factors by itself
+    //  -- no block barrier before the row sums -- takes the riding combine as long as this: the two
+    //  barriers it saves cost what its 4x redundant exponentials do, 5.9 us either way)
+    float beta, nabla;
     float v[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + NRG * j;
-        v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
-    }
     float uin = 0.0f;
-    if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
-
-    MPPI_CSTAMP(1);
-    float mloc = mreg[0];
+    {
+        float mreg[PT], sreg[PT];
+        const int jmax = (a.n_parts + THREADS - 1) / THREADS;   // sweeps that hold any partial at all
 #pragma unroll
-    for (int j = 1; j < PT; ++j) mloc = fminf(mloc, mreg[j]);
-    mloc = wave_min(mloc);
-    if (lane == 0) scal[wave] = mloc;
-    __syncthreads();
-    float beta = scal[0];
-#pragma unroll
-    for (int i = 1; i < NW; ++i) beta = fminf(beta, scal[i]);
-
-    float sloc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        if (j < jmax) {      // block-uniform: no exponentials for sweeps without partials
+        for (int j = 0; j < PT; ++j) {
             const int p = tid + j * THREADS;
-            const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
-            if (p < a.n_parts) r_lds[p] = r;
-            sloc += r * sreg[j];
+            mreg[j] = INFINITY;
+            sreg[j] = 0.0f;
+            if (j < jmax) {                                      // block-uniform
+                mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
+                sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
+            }
         }
-    }
-    sloc = wave_sum(sloc);
-    if (lane == 0) scal[NW + wave] = sloc;
-    __syncthreads();
-    float nabla = 0.0f;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) nabla += scal[NW + i];
+        for (int j = 0; j < NR; ++j) {
+            const int p = p_begin + rgrp + NRG * j;
+            v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
+        }
+        if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
+
+        MPPI_CSTAMP(1);
+        float mloc = mreg[0];
+#pragma unroll
+        for (int j = 1; j < PT; ++j)
+            if (j < jmax) mloc = fminf(mloc, mreg[j]);
+        mloc = wave_min(mloc);
+        if (lane == 0) scal[wave] = mloc;
+        __syncthreads();
+        beta = scal[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) beta = fminf(beta, scal[i]);
+        MPPI_CSTAMP(5);
+
+        float sloc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            if (j < jmax) {      // block-uniform: no exponentials for sweeps without partials
+                const int p = tid + j * THREADS;
+                const float r = (mreg[j] < INFINITY) ? expf(-a.inv_lambda * (mreg[j] - beta)) : 0.0f;
+                if (p < a.n_parts) r_lds[p] = r;
+                sloc += r * sreg[j];
+            }
+        }
+        sloc = wave_sum(sloc);
+        if (lane == 0) scal[NW + wave] = sloc;
+        __syncthreads();
+        nabla = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) nabla += scal[NW + i];
+    }
 
     MPPI_CSTAMP(2);
-    float acc = 0.0f;
+#ifdef MPPI_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // analysis: when have ALL row loads landed?
+    MPPI_CSTAMP(6);
+#endif
+    // row sums: four accumulators (the additions of a lane do not wait for each other); a row past
+    // the split's end was loaded as 0 and takes a finite factor (index clamped), so no test per row
+    float acc;
+    {
+        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int p_top = a.n_parts - 1;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int p = p_begin + rgrp + NRG * j;
-        if (p < p_end) acc = fmaf(r_lds[p], v[j], acc);
+        for (int j = 0; j < NR; ++j) {
+            const int p = min(p_begin + rgrp + NRG * j, p_top);
+            a4[j & 3] = fmaf(r_lds[p], v[j], a4[j & 3]);
+        }
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     if (n < a.TA) {      // rows beyond the first batch (only when RS hit its cap)
         for (int p0 = p_begin + rgrp + NRG * NR; p0 < p_end; p0 += NRG * NR) {
@@ -326,11 +345,15 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
         }
     }
     red[rgrp * kCombineCols + col] = acc;
+    MPPI_CSTAMP(7);
     __syncthreads();
     float tot = 0.0f;
-    if (wave == 0) {       // both halves of the wave compute the same 32 sums, in row-group order
+    if (wave == 0) {       // both halves of the wave compute the same 32 sums: four running sums over
+                           // the row groups rg = 0, 4, 8, .. / 1, 5, .. / .., added pairwise at the end
+        float t4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int rg = 0; rg < NRG; ++rg) tot += red[rg * kCombineCols + col];
+        for (int rg = 0; rg < NRG; ++rg) t4[rg & 3] += red[rg * kCombineCols + col];
+        tot = (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
 
     MPPI_CSTAMP(3);
