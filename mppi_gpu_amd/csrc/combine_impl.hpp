@@ -261,25 +261,63 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
     float beta, nabla;
     float v[NR];
     float uin = 0.0f;
+#ifdef MPPI_TRACE
+    if (a.n_parts > 0) MPPI_CSTAMP(8);        // (the kernel arguments have arrived)
+#endif
+    // The requests themselves are the first thing on the path between two solves, and a lone wave
+    // issues one instruction every ~10-20 cycles (cold instruction cache, a SIMD shared with the
+    // next solve's noise): as plain indexed loads -- 64-bit address arithmetic and an exec-masked
+    // branch per element -- they were 890 instructions and 2.0 us before the first barrier.  Raw
+    // BUFFER loads instead: the descriptors are wave-uniform (SGPRs), the lane part of the offset
+    // is computed once, the sweep / row part is an SGPR offset, and a request past the end of the
+    // buffer returns 0 by itself (no bounds test, no branch): two instructions per element.
     {
         float mreg[PT], sreg[PT];
         const int jmax = (a.n_parts + THREADS - 1) / THREADS;   // sweeps that hold any partial at all
+        const unsigned int m_step = (unsigned int)a.m_stride * 4u, s_step = (unsigned int)a.s_stride * 4u;
+        const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.m), 0, (int)((unsigned int)(a.n_parts - 1) * m_step + 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.s), 0, (int)((unsigned int)(a.n_parts - 1) * s_step + 4u), 0x00020000);
+        const unsigned int m_off = (unsigned int)tid * m_step, s_off = (unsigned int)tid * s_step;
+        auto sweep = [&](int j) {
+            mreg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                m_rsrc, m_off, (unsigned int)(j * THREADS) * m_step, 0));
+            sreg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                s_rsrc, s_off, (unsigned int)(j * THREADS) * s_step, 0));      // past the end: 0
+        };
+        constexpr int PT0 = PT < 4 ? PT : 4;     // the sweeps of up to 4 * THREADS partials: no test
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int p = tid + j * THREADS;
-            mreg[j] = INFINITY;
-            sreg[j] = 0.0f;
-            if (j < jmax) {                                      // block-uniform
-                mreg[j] = (p < a.n_parts) ? a.m[(size_t)p * a.m_stride] : INFINITY;
-                sreg[j] = (p < a.n_parts) ? a.s[(size_t)p * a.s_stride] : 0.0f;
-            }
+        for (int j = 0; j < PT; ++j) { mreg[j] = INFINITY; sreg[j] = 0.0f; }
+#pragma unroll
+        for (int j = 0; j < PT0; ++j) sweep(j);
+        if (jmax > PT0) {                                        // block-uniform
+#pragma unroll
+            for (int j = PT0; j < PT; ++j)
+                if (j < jmax) sweep(j);
         }
+        MPPI_CSTAMP(9);                       // (partial minima / exp-sums requested)
+        {
+            const int rows = p_end - p_begin;                    // rows of this split (may be <= 0)
+            const unsigned int n_step = (unsigned int)a.N_stride * 4u;
+            const __amdgpu_buffer_rsrc_t n_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.N + (size_t)(rows > 0 ? p_begin : 0) * a.N_stride), 0,
+                rows > 0 ? (int)((unsigned int)(rows - 1) * n_step + (unsigned int)a.TA * 4u) : 0,
+                0x00020000);
+            // (a column n >= TA of the last column block reads the head of the next row, or 0
+            //  past the last row: its sums are never applied)
+            const unsigned int n_off = (unsigned int)rgrp * n_step + (unsigned int)n * 4u;
 #pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            const int p = p_begin + rgrp + NRG * j;
-            v[j] = (p < p_end && n < a.TA) ? a.N[(size_t)p * a.N_stride + n] : 0.0f;
+            for (int j = 0; j < NR; ++j)
+                v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    n_rsrc, n_off, (unsigned int)(NRG * j) * n_step, 0));
         }
         if (a.final_mode != 0 && wave == 0 && n < a.TA) uin = a.U[(a.solve_idx & 1ull) * a.TA + n];
+
+        // (sweeps past the last partial asked for nothing or got 0: their minimum is +inf)
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+            if (tid + j * THREADS >= a.n_parts) mreg[j] = INFINITY;
 
         MPPI_CSTAMP(1);
         float mloc = mreg[0];

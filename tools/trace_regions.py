@@ -50,7 +50,7 @@ if nb:
     print("combine-role blocks:", nb, " start (10 ns ticks after first block) p50/max",
           np.median(tc[:, 0] - t00), (tc[:, 0] - t00).max(), " end p50/max",
           np.median(tc[:, 10] - t00), (tc[:, 10] - t00).max())
-    for i, nm in [(1, "loads landed (m,s)"), (5, "beta known"), (2, "beta/nabla done"), (6, "row loads landed"),
+    for i, nm in [(8, "kernel arguments in"), (9, "m, s requested"), (1, "all loads requested"), (5, "beta known"), (2, "beta/nabla done"), (6, "row loads landed"),
                   (7, "row sums in LDS"), (3, "rows reduced"), (4, "splits met"), (10, "done")]:
         r = tc[:, i] - tc[:, 0]
         r = r[tc[:, i] > 0]
