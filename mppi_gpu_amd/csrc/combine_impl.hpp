@@ -136,8 +136,9 @@ __device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int
     }
     if (n < a.TA) {
         const float unew = updated_control(a, n, uin, tot, nabla);
-        publish_control(a, n, unew);
+        // (the tagged word first: a rollout block of a riding launch is waiting for it)
         if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        publish_control(a, n, unew);
     }
     if (cb == 0 && tid == 0) {
         a.dev->beta = beta;
@@ -150,8 +151,9 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float
 {
     if (a.final_mode) {
         const float unew = updated_control(a, n, uin, tot, nabla);
-        publish_control(a, n, unew);
+        // (the tagged word first: a rollout block of a riding launch is waiting for it)
         if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        publish_control(a, n, unew);
     } else {
         a.partial_out[2 + n] = tot;
     }
@@ -207,7 +209,7 @@ __device__ __forceinline__ void ride_fetch_controls(const RolloutArgs& g, const 
                 timed_out = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {

@@ -319,8 +319,10 @@ __device__ __forceinline__ float tile_min(float cost_or_inf, float* misc, int wa
 //   misc : [8] LDS floats, wsum : [4][TAp] LDS, nrun : [TAp] LDS (thread n owns nrun[n])
 __device__ __forceinline__ void fold_tile(RunState& rs, float m_t, const float* misc,
                                           const float* wsum, float* nrun, int TAp, int TA,
-                                          float inv_lambda, bool first)
-{
+                                          float inv_lambda, bool first, float* nout = nullptr)
+{   // nout != null (block-uniform; the block's LAST tile): the folded sums go straight to the block
+    // partial in global memory instead of back into nrun -- no LDS round trip, no barrier, no copy
+    // loop between the last tile and the end of the block
     const float s_t = ((misc[4] + misc[5]) + misc[6]) + misc[7];
     float alpha, gamma;
     float Mn;
@@ -334,7 +336,9 @@ __device__ __forceinline__ void fold_tile(RunState& rs, float m_t, const float* 
     for (int n = threadIdx.x; n < TA; n += kRolloutThreads) {
         const float tot = ((wsum[n] + wsum[TAp + n]) + wsum[2 * TAp + n]) + wsum[3 * TAp + n];
         const float old = first ? 0.0f : nrun[n];
-        nrun[n] = alpha * old + gamma * tot;
+        const float val = alpha * old + gamma * tot;
+        if (nout) nout[n] = val;
+        else nrun[n] = val;
     }
     rs.S = first ? s_t : alpha * rs.S + gamma * s_t;
     rs.M = Mn;

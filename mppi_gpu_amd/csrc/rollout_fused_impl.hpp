@@ -8,6 +8,9 @@
 #ifndef MPPI_FUSED_SCALED
 #define MPPI_FUSED_SCALED 1    // pass 2 on the scaled state (7 instead of 11 VALU per normal)
 #endif
+#ifndef MPPI_FUSED_DIRECT_FOLD
+#define MPPI_FUSED_DIRECT_FOLD 1   // the block's last tile folds straight into the global partial
+#endif
 #ifndef MPPI_FUSED_PRIO
 #define MPPI_FUSED_PRIO 2      // s_setprio of the passes after the Philox pass (which runs at 0)
 #endif
@@ -136,6 +139,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
 
     RunState rs{INFINITY, 0.0f};
     bool first = true;
+    float* const Nout = g.part_N + (size_t)bid * TA;     // this block's partial sums
 
     for (int tb = bid; tb < n_tileblk; tb += nblk) {
         const long long gid = (long long)tb * kRolloutThreads + threadIdx.x;
@@ -502,16 +506,22 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         if (first) MPPI_STAMP(6);
         __syncthreads();
         if (first) MPPI_STAMP(7);
-        fold_tile(rs, m_t, misc, wsum, nrun, TAp, TA, inv_lambda, first);
+        // (the block's last tile folds straight into the block partial in global memory)
+        const bool last_tile = MPPI_FUSED_DIRECT_FOLD && tb + nblk >= n_tileblk;
+        fold_tile(rs, m_t, misc, wsum, nrun, TAp, TA, inv_lambda, first, last_tile ? Nout : nullptr);
         if (first) MPPI_STAMP(8);
         first = false;
-        __syncthreads();
+        if (!last_tile) __syncthreads();
     }
     MPPI_STAMP(9);
 
     // ---- publish the block partial ----------------------------------------------------------
-    float* Nout = g.part_N + (size_t)bid * TA;
+#if MPPI_FUSED_DIRECT_FOLD
+    if (first)          // (a block without a tile: the grid never has one, kept for safety)
+        for (int n = threadIdx.x; n < TA; n += kRolloutThreads) Nout[n] = 0.0f;
+#else
     for (int n = threadIdx.x; n < TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
+#endif
     if (threadIdx.x == 0) {
         g.part_m[bid] = rs.M;
         g.part_s[bid] = rs.S;
