@@ -5,6 +5,18 @@
 #pragma once
 #include "device_common.hpp"
 
+// How a rollout block of a riding launch polls for its controls (tools/mkvariant.sh, tools/abn.sh on
+// one box, C2): asking for the watchdog word WITH every batch halves the poll period and makes the
+// solve SLOWER (12.67 against 12.41 us: 625 blocks looking at the same 3.2 KB more often stand in the
+// way of the 50 blocks that write it); pauses of 1 / 8 / 16 / 32 between polls: 12.38 / 12.43 /
+// 12.33 / 12.29 us -- flat; the short pause keeps the worst case of a late look small.
+#ifndef MPPI_POLL_WD_BATCH
+#define MPPI_POLL_WD_BATCH 0   // 1: the watchdog word is requested with every poll batch, not after it
+#endif
+#ifndef MPPI_POLL_SLEEP
+#define MPPI_POLL_SLEEP 1      // s_sleep between two polls of a rollout block waiting for its controls
+#endif
+
 namespace mppi {
 
 struct CombineSmem {     // LDS of one combine block; carve from static or dynamic shared memory
@@ -195,6 +207,12 @@ __device__ __forceinline__ void ride_fetch_controls(const RolloutArgs& g, const 
                                : __hip_atomic_load(fin_p + n, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (the watchdog word travels WITH the batch: asked for after the check it is a second
+            //  memory round trip per poll, and the poll period is what a waiting block loses on
+            //  average between the word's arrival and its own next look)
+#if MPPI_POLL_WD_BATCH
+            const bool tripped = watchdog_tripped(g.err_dev);
+#endif
             bool all = true;
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
@@ -205,11 +223,14 @@ __device__ __forceinline__ void ride_fetch_controls(const RolloutArgs& g, const 
                 all = all && have[j];
             }
             if (all) break;
-            if (wall_clock64() - t0 > limit || watchdog_tripped(g.err_dev)) {
+#if !MPPI_POLL_WD_BATCH
+            const bool tripped = watchdog_tripped(g.err_dev);
+#endif
+            if (wall_clock64() - t0 > limit || tripped) {
                 timed_out = true;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(MPPI_POLL_SLEEP);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
