@@ -363,6 +363,7 @@ def main():
     if not args.no_events:
         m.set_profiling(max(1, args.event_every))
     fence()
+    cnt0 = m.launch_counts()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -378,9 +379,10 @@ def main():
 
     roof = None
     # mode 0 lets the combine ride in the next rollout launch while launches are short (at most two
-    # tiles per block, engine.hip enqueue_rollout); longer ones launch it on its own
-    riding = (args.pipeline == 0 and not args.strict and not args.blocking
-              and geo["tile_groups"] <= 2 * geo["grid"])
+    # tiles per block) and all their blocks fit the chip at once (engine.hip enqueue_rollout); the
+    # engine's own launch counters say what happened in the timed region
+    cnt1 = m.launch_counts()
+    riding = cnt1["riding"] - cnt0["riding"] > (cnt1["rollout"] - cnt0["rollout"]) // 2
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
@@ -480,7 +482,8 @@ def main():
             m3.memcpy_set_data(c3["x0"], c3["U"], c3["goal"], c3["w"])
             geo3 = m3.geometry()
             dt3, k3, kn3, cm3 = timed_engine_run(m3, 60, 400)
-            riding3 = geo3["tile_groups"] <= 2 * geo3["grid"]
+            c3c = m3.launch_counts()
+            riding3 = c3c["riding"] > c3c["rollout"] // 2
             extra["c3"] = {"workload": desc3, "ms_per_step": dt3 * 1e3, "value": K3 / dt3,
                            "unit": "rollouts/s", "steps": 400, "geometry": geo3,
                            "roofline": roofline_entry("c3", K3, T3, A3, geo3, riding3, k3, kn3, cm3)}
@@ -535,7 +538,8 @@ def main():
                         "what": {"direct": "combine kernel -> peer inboxes over xGMI (hipIpc), no collective",
                                  "collective": "RCCL all-gather of T*A+2 floats"}[sharded.transport],
                         "validated_against_collective": getattr(sharded, "validated", None)},
-                       "geometry": geo, "rollout_steps_per_s": value * T},
+                       "geometry": geo, "rollout_steps_per_s": value * T,
+                       "launches_in_timed_region": {k: cnt1[k] - cnt0[k] for k in ("rollout", "riding", "combine")}},
             "roofline": roof,
             "latency": latency,
         }

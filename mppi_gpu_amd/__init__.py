@@ -195,6 +195,13 @@ class PointMassModel:
                 "packed": bool(lay[0]), "groups_per_lane": lay[1], "trajectories_per_wave": lay[2],
                 "tile_groups": lay[3]}
 
+    def launch_counts(self):
+        """Launches since creation: rollout launches, those that carried a riding combine,
+        stand-alone combine launches, and the blocks of the riding kernel the chip holds at once."""
+        c = (C.c_longlong * 4)()
+        check(self._lib.mppi_get_launch_counts(self._h, c))
+        return {"rollout": c[0], "riding": c[1], "combine": c[2], "resident_ride": c[3]}
+
     # -- asynchronous / sharded ---------------------------------------------------------------
     def solve_async(self, stream=None):
         check(self._lib.mppi_solve_async(self._h, C.c_void_p(stream or 0)))

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mppi_set_profiling": (C.c_int, [engine_p, C.c_int]),
     "mppi_kernel_ms": (C.c_int, [engine_p, C.c_int, c_double_p, c_int_p]),
     "mppi_get_geometry": (C.c_int, [engine_p, c_int_p]),
+    "mppi_get_launch_counts": (C.c_int, [engine_p, C.POINTER(C.c_longlong)]),
     "mppi_cpu_create": (C.c_void_p, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int]),
     "mppi_cpu_destroy": (None, [C.c_void_p]),
     "mppi_cpu_set_data": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p]),

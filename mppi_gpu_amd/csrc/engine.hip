@@ -94,6 +94,9 @@ struct mppi_engine {
     int tune_combine_splits = 0;            // MPPI_COMBINE_SPLITS: row splits of the combine, 0 = auto
     int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
     long long resident_ride = 0;            // blocks of the riding kernel variant the chip holds at once
+    long long n_rollout_launches = 0;       // since creation: rollout launches, those that carried a
+    long long n_riding_launches = 0;        // combine, and combines launched on their own
+    long long n_combine_launches = 0;       // (mppi_get_launch_counts)
 
     // geometry
     int user_chunks = 0, user_strict = 0, user_max_blocks = 0;
@@ -537,6 +540,7 @@ int flush_pending(mppi_engine_t* e)
     ca.trace = nullptr;      // the analysis looks at the riding role only
 #endif
     HIPCHK(mppi::launch_combine_small(ca, e->pending_stream, tm));
+    e->n_combine_launches += 1;
     return MPPI_OK;
 }
 
@@ -652,7 +656,9 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         fill_own_combine(e, dc.c, e->pending_idx, e->u_epoch, e->pending_mode, e->pending_xseq);
         dc.n_blocks = dc.c.n_cols * dc.c.RS;
         e->pending = false;
+        e->n_riding_launches += 1;
     }
+    e->n_rollout_launches += 1;
     {   // every n-th solve AND its successor: a stamp is clean only behind a stamped predecessor
         const unsigned long long ph = e->prof > 0 ? e->prof_count++ % (unsigned long long)e->prof : 2;
         e->prof_now = e->prof > 0 && (ph == 0 || (ph == 1 && e->prof > 2));
@@ -1431,6 +1437,18 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out)
     }
     *avg_ms = n ? tot / n : 0.0;
     *n_out = n;
+    return MPPI_OK;
+}
+
+int mppi_get_launch_counts(mppi_engine* e, long long out[4])
+{
+    if (!e || !out) return fail(MPPI_EINVAL, "null argument");
+    int rc = ensure_geometry(e);
+    if (rc) return rc;
+    out[0] = e->n_rollout_launches;
+    out[1] = e->n_riding_launches;
+    out[2] = e->n_combine_launches;
+    out[3] = e->resident_ride;
     return MPPI_OK;
 }
 

@@ -482,6 +482,32 @@ def test_packed_kernel_rides_and_flushes_with_equal_bits(gpu, A, K, T, ngl):
 
 
 @pytest.mark.gpu
+def test_a_combine_rides_only_where_the_whole_launch_is_resident(gpu):
+    """mppi_get_launch_counts: back-to-back solves of a short launch whose blocks all fit the chip
+    (BASELINE config 2: 625 rollout + 50 combine blocks) are one launch each; a launch of the same
+    tile length with more blocks than the chip holds at once launches its combines on their own --
+    the rollout blocks of a riding launch WAIT for its combine blocks, so none may be left
+    without a slot.  Equal results either way are the business of the equal-bits tests."""
+    n = 12
+    for A, K, T, expect_ride in [(2, 10000, 200, True), (2, 40000, 200, False)]:
+        c = ol.make_case(A, 1, T, seed=5, u_scale=0.0)
+        with _model(gpu, A, K, T, c) as m:
+            m.set_packing(-1)
+            geo = m.geometry()
+            for _ in range(n):
+                m.solve_async()
+            m.sync_act()
+            cnt = m.launch_counts()
+        assert cnt["rollout"] == n and cnt["resident_ride"] > 0, cnt
+        assert geo["tile_groups"] <= 2 * geo["grid"], geo            # short launches both
+        if expect_ride:
+            assert geo["grid"] + 50 <= cnt["resident_ride"], (geo, cnt)
+            assert cnt["riding"] == n - 1 and cnt["combine"] == 1, cnt
+        else:
+            assert geo["grid"] > cnt["resident_ride"], (geo, cnt)
+            assert cnt["riding"] == 0 and cnt["combine"] == n, cnt
+
+
 def test_deferred_combine_interleaved_with_everything_else(gpu):
     """A pending combine must be flushed by every call that reads or changes what it touches:
     set_x between asynchronous solves (rides on), get_u / get_inf / set_params / set_tuning /
