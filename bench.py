@@ -404,7 +404,7 @@ def main():
                             "rollout_frac": round(ab / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                             if r_ms > 0 else None}
     m.set_profiling(0)
-    if roof is not None and rank == 0 and not args.rehearse_one_gpu:
+    if roof is not None and not args.rehearse_one_gpu:      # (every rank, on its own GPU: the ranks stay in step)
         pk = measured_hbm_peak(torch)
         roof["peak_measured"] = pk
         if pk["copy_GBs"] > 0:
