@@ -338,6 +338,7 @@ def main():
         step = m.get_act if sharded is None else sharded.get_act
 
     def fence():
+        m.flush_async()       # nothing held back: a deferred combine is on its stream before the waits
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
