@@ -4,6 +4,7 @@
 #pragma once
 #include "device_common.hpp"
 #include "combine_impl.hpp"
+#include <type_traits>
 
 #ifndef MPPI_FUSED_SCALED
 #define MPPI_FUSED_SCALED 1    // pass 2 on the scaled state (7 instead of 11 VALU per normal)
@@ -320,7 +321,11 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         //      summed.  No per-step masking: the chunk that holds step T-1 takes a snapshot (cost
         //      so far, state) at the wave-uniform step n_last and uses that. -----------------------
         float cpart = 0.0f;
-        {
+        // (the drift term cg of a velocity goal != 0 is a SEPARATE copy of the pass behind one
+        //  wave-uniform branch: tested inside the step loop, hipcc makes an addition and a select
+        //  per normal of it)
+        auto pass2_scaled = [&](auto cg_tag) {
+            constexpr bool CG = decltype(cg_tag)::value;
             float dps[A], dvs[A], ru[A], rp[A], rv[A];
 #pragma unroll
             for (int i = 0; i < A; ++i) {
@@ -358,7 +363,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         for (int i = 0; i < A; ++i) {
                             const float a = u[s * A + i] + es[i];
                             float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
-                            if (has_cg) pn += P.cg[i];
+                            if constexpr (CG) pn += P.cg[i];
                             dvs[i] = fmaf(P.k3[i], a, dvs[i]);
                             dps[i] = pn;
                             ru[i] = fmaf(uc[s * A + i], es[i], ru[i]);
@@ -380,7 +385,9 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                 }
             }
             cpart = signed_total();
-        }
+        };
+        if (has_cg) pass2_scaled(std::true_type());
+        else pass2_scaled(std::false_type());
         {
             const float cT = snap[0];
             float fc = 0.0f;    // Cost::final_cost (src/cost.cu:57-64) on the state after step T-1

@@ -387,8 +387,13 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         //      src/cost.cu:42-55).  One cost accumulator per axis; where a trajectory ends inside
         //      a lane, its sum (+ Cost::final_cost, src/cost.cu:57-64) is set aside and the lane
         //      goes on from x0 with the next trajectory. ----------------------------------------
+        // (the drift term cg of a velocity goal != 0 is compiled as a SEPARATE copy of the pass,
+        //  chosen by one wave-uniform branch: tested inside the step loop, hipcc turns the test into
+        //  an addition and a select per normal -- 96 VALU instructions per tile, 5 % of them)
+        float cH = 0.0f, c_last = 0.0f;
+        auto pass2 = [&](auto cg_tag) {
+            constexpr bool CG = decltype(cg_tag)::value;
         float racc[A];
-        float cH = 0.0f;
 #pragma unroll
         for (int i = 0; i < A; ++i) racc[i] = 0.0f;
 #if MPPI_PK_RACC3
@@ -431,7 +436,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 for (int i = 0; i < A; ++i) {
                     const float a = u[s * A + i] + es[i];
                     float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
-                    if (has_cg) pn += P.cg[i];
+                    if constexpr (CG) pn += P.cg[i];
                     dvs[i] = fmaf(P.k3[i], a, dvs[i]);
                     dps[i] = pn;
 #if MPPI_PK_RACC3
@@ -469,7 +474,6 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 }
             }
         }
-        float c_last = 0.0f;
         {
             const bool term = !tail_slot && ends_head;    // the trajectory ends with the lane
 #pragma unroll
@@ -481,6 +485,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 c_last += racc[i] + (term ? fc : 0.0f);
             }
         }
+        };
+        if (has_cg) pass2(std::true_type());
+        else pass2(std::false_type());
         const float cA = tail_slot ? cH : c_last;         // my part of trajectory j0
         MPPI_PK_STAMP(4);
 
