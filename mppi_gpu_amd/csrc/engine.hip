@@ -252,7 +252,7 @@ int ensure_geometry(mppi_engine_t* e)
         packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
         // Packing buys throughput: fewer, fuller tiles.  A launch so short that no block would walk
         // a second tile (K = 1e4, 2-D: 500 tile groups) is a latency problem instead, and there
-        // the row-aligned kernel's shorter tail wins (measured 13.2 against 14.7 us at C2).
+        // the row-aligned kernel's shorter tail wins (measured 12.0 against 14.4 us at C2).
         if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
             packed = false;
         if (packed && e->user_packing <= 0 &&
