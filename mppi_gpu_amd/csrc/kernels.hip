@@ -456,9 +456,9 @@ int combine_small_prepare(CombineArgs& a)
 {
     constexpr int kRowGroups = (kRolloutThreads / 64) * (64 / kCombineCols);
     const int cols = (a.TA + kCombineCols - 1) / kCombineCols;
-    // ~20 rows per lane and split (measured flat between 10 and 40, MI355X), at most
-    // kMaxSmallSplits splits
-    int rs = a.row_splits > 0 ? a.row_splits : (a.n_parts + kRowGroups * 20 - 1) / (kRowGroups * 20);
+    // up to kSmallCombineNR rows per lane and split, all in flight at once, at most kMaxSmallSplits
+    // splits (a second split is a store -> poll hop: one split for as long as the rows fit)
+    int rs = a.row_splits > 0 ? a.row_splits : (a.n_parts + kRowGroups * kSmallCombineNR - 1) / (kRowGroups * kSmallCombineNR);
     if (rs < 1) rs = 1;
     if (rs > kMaxSmallSplits) rs = kMaxSmallSplits;
     a.n_cols = cols;

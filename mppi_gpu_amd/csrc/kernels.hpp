@@ -234,16 +234,19 @@ struct DeferredCombine {
 
 constexpr int kRolloutThreads = 256;
 constexpr int kCombineThreads = 1024;
-constexpr int kCombineCols = 8;    // columns of U per combine block: with 8 (eight rows per
-                                   // wave-instruction) 625 block partials fit ONE row split of the
-                                   // 256-thread combine, so the riding combine has no split meeting
-                                   // (a store -> poll hop): C2 13.8 -> 13.5 us per solve, the
-                                   // stand-alone combine 6.1 -> 5.3 us at C3
+constexpr int kCombineCols = 16;   // columns of U per combine block = 64-byte pieces of a partial row
+                                   // (four rows per wave-instruction).  With kSmallCombineNR = 40 rows
+                                   // in flight per lane the 625 block partials of C2 fit ONE row split
+                                   // of the 256-thread combine (no split meeting: a store -> poll hop).
+                                   // Measured at C2, riding: 4 columns 13.45, 8 columns 12.03,
+                                   // 16 columns 11.8 us per solve -- half-line pieces cost the CUs
+                                   // that host the combine role twice the requests, on a memory
+                                   // pipeline the rollout blocks' noise stores are using
 constexpr int kMaxParts = 4096;   // LDS r[] capacity in the combine kernel
 constexpr int kMaxRowSplits = 32;
 constexpr int kMaxRanks = 64;     // rank partials one combine block can hold (LDS xv[][16])
-constexpr int kSmallCombineNR = 24;   // row loads in flight per lane of the 256-thread combine
-                                      // (16 row groups per block: up to 384 rows per split)
+constexpr int kSmallCombineNR = 40;   // row loads in flight per lane of the 256-thread combine
+                                      // (16 row groups per block: up to 640 rows per split)
 constexpr int kMaxSmallSplits = 8;    // row splits of the 256-thread combine (one poll batch)
 
 // Optional dispatch timing: when both events are non-null the launch goes through

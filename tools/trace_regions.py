@@ -38,8 +38,8 @@ if ride:
         m.solve_async()                              # the last launch carried a combine
     m.sync_act()
     import math
-    rs = min(8, max(1, math.ceil(grid / 320)))
-    nb = math.ceil(T * A / 16) * rs
+    rs = min(8, max(1, math.ceil(grid / 640)))      # 16 row groups x 40 rows per lane and split
+    nb = math.ceil(T * A / 16) * rs                  # kCombineCols = 16
 else:
     m.solve_async(); m.sync_act()
 buf = np.zeros((grid + nb, 16), np.uint64)
