@@ -9,7 +9,8 @@
 // one box, C2): asking for the watchdog word WITH every batch halves the poll period and makes the
 // solve SLOWER (12.67 against 12.41 us: 625 blocks looking at the same 3.2 KB more often stand in the
 // way of the 50 blocks that write it); pauses of 1 / 8 / 16 / 32 between polls: 12.38 / 12.43 /
-// 12.33 / 12.29 us -- flat; the short pause keeps the worst case of a late look small.
+// 12.33 / 12.29 us -- flat; the short pause keeps the worst case of a late look small.  A pause
+// BEFORE the first look (0.9 / 1.7 / 2.7 us): 12.0 / 12.5 / 13.4 against 11.95 us -- no gain.
 #ifndef MPPI_POLL_WD_BATCH
 #define MPPI_POLL_WD_BATCH 0   // 1: the watchdog word is requested with every poll batch, not after it
 #endif
