@@ -46,6 +46,9 @@
 #ifndef MPPI_PK_RACC3
 #define MPPI_PK_RACC3 1        // three cost accumulators per axis (shorter dependent chains)
 #endif
+#ifndef MPPI_PK_QSCAN
+#define MPPI_PK_QSCAN 1        // per-tile scans on tile-invariant absorb masks, responses summed at a common time
+#endif
 #ifndef MPPI_PK_NOMINAL
 #define MPPI_PK_NOMINAL 1      // lane start states = nominal trajectory (once per block) + response to the noise
 #endif
@@ -149,6 +152,38 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         }
     }
     const unsigned long long blk_base = h.solve_idx * (unsigned long long)NBT;
+#if MPPI_PK_QSCAN
+    // What the segmented scans of a tile decide is the same for every tile: whether this lane, at
+    // level d of the scan, takes in what sits d lanes to its left ("a trajectory starts in my
+    // range" flags only) -- worked out ONCE, one bit per level.  And with every range's position
+    // response carried forward to ONE reference time (the end of the trajectory: Q = P + (R - E) dt V,
+    // E = step at which the range ends), responses ADD: the scan needs no step counts and no
+    // per-level time shift, and a lane gets its start state back as Qex - (R - S) dt Vex, S = the
+    // step its head starts at.  Per tile and level: 6 DPP moves + 6 additions instead of 8 moves,
+    // a conversion, a multiply, 3 FMAs, 7 additions and the flag bookkeeping.  (Used for the
+    // response to the NOISE -- small numbers; the once-per-block nominal pass keeps the plain
+    // form, whose sums do not cancel.)
+    unsigned int absorb = 0;
+    {
+        int flg = flag0;
+        const int cr = lane & 15;
+#define MPPI_PK_ABS(BIT, COND, GETI)                                                \
+        {                                                                           \
+            const int fl = GETI(flg);                                               \
+            if ((COND) && flg == 0) { absorb |= (BIT); flg = fl; }                  \
+        }
+        MPPI_PK_ABS(1u, cr >= 1, dppi<MPPI_ROW_SHR(1)>)
+        MPPI_PK_ABS(2u, cr >= 2, dppi<MPPI_ROW_SHR(2)>)
+        MPPI_PK_ABS(4u, cr >= 4, dppi<MPPI_ROW_SHR(4)>)
+        MPPI_PK_ABS(8u, cr >= 8, dppi<MPPI_ROW_SHR(8)>)
+        MPPI_PK_ABS(16u, (lane & 16) != 0, (dpp_rows_i<kRowBcast15, 0xA>))
+        MPPI_PK_ABS(32u, (lane & 32) != 0, (dpp_rows_i<kRowBcast31, 0xC>))
+#undef MPPI_PK_ABS
+    }
+    // steps from the end of the range handed on / from the start of the head to the end of the trajectory
+    const float q_ref = (float)(NGT * SG - (tail_slot ? n_out : r0 * SG + L)) * P.dt;
+    const float c_ref = (float)(NGT * SG - r0 * SG) * P.dt;
+#endif
 #if MPPI_PK_NOMINAL
     float dps_nom[A], dvs_nom[A];
 #pragma unroll
@@ -333,6 +368,44 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 Vz[i] = P.dt * S1o;
                 Pz[i] = fmaf(P.dt2, fmaf(no - 1.0f, S1o, -S2o), P.B0 * S1o);
             }
+#if MPPI_PK_QSCAN
+            if constexpr (MODE == 2) {
+                float Qz[A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) Qz[i] = fmaf(q_ref, Vz[i], Pz[i]);
+#define MPPI_PK_QSUM(BIT, GETF)                                                     \
+                {                                                                   \
+                    float Ql[A], Vl[A];                                             \
+                    _Pragma("unroll") for (int i = 0; i < A; ++i) {                 \
+                        Ql[i] = GETF(Qz[i]);                                        \
+                        Vl[i] = GETF(Vz[i]);                                        \
+                    }                                                               \
+                    if (absorb & (BIT)) {                                           \
+                        _Pragma("unroll") for (int i = 0; i < A; ++i) {             \
+                            Qz[i] = Ql[i] + Qz[i];                                  \
+                            Vz[i] = Vl[i] + Vz[i];                                  \
+                        }                                                           \
+                    }                                                               \
+                }
+                MPPI_PK_QSUM(1u, dpp<MPPI_ROW_SHR(1)>)
+                MPPI_PK_QSUM(2u, dpp<MPPI_ROW_SHR(2)>)
+                MPPI_PK_QSUM(4u, dpp<MPPI_ROW_SHR(4)>)
+                MPPI_PK_QSUM(8u, dpp<MPPI_ROW_SHR(8)>)
+                MPPI_PK_QSUM(16u, (dpp_rows<kRowBcast15, 0xA>))
+                MPPI_PK_QSUM(32u, (dpp_rows<kRowBcast31, 0xC>))
+#undef MPPI_PK_QSUM
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    float Qex = dpp<kWaveShr1>(Qz[i]);
+                    float Vex = dpp<kWaveShr1>(Vz[i]);
+                    if (starts0) { Qex = 0.f; Vex = 0.f; }
+                    const float Pex = fmaf(-c_ref, Vex, Qex);
+                    dps[i] = fmaf(P.sp[i], Pex, bp[i]);
+                    dvs[i] = fmaf(P.sv[i], Vex, bv[i]);
+                }
+                return;
+            }
+#endif
             {
                 int nacc = n_out, flg = flag0;
                 const int cr = lane & 15;
@@ -495,6 +568,20 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         float ctA, ctB;
         {
             float cz = c_last;                            // the range handed on (tail, or all)
+#if MPPI_PK_QSCAN
+#define MPPI_PK_CSUMQ(BIT, GETF)                                                    \
+            {                                                                       \
+                const float cl = GETF(cz);                                          \
+                if (absorb & (BIT)) cz = cl + cz;                                   \
+            }
+            MPPI_PK_CSUMQ(1u, dpp<MPPI_ROW_SHR(1)>)
+            MPPI_PK_CSUMQ(2u, dpp<MPPI_ROW_SHR(2)>)
+            MPPI_PK_CSUMQ(4u, dpp<MPPI_ROW_SHR(4)>)
+            MPPI_PK_CSUMQ(8u, dpp<MPPI_ROW_SHR(8)>)
+            MPPI_PK_CSUMQ(16u, (dpp_rows<kRowBcast15, 0xA>))
+            MPPI_PK_CSUMQ(32u, (dpp_rows<kRowBcast31, 0xC>))
+#undef MPPI_PK_CSUMQ
+#else
             int flg = flag0;
             const int cr = lane & 15;
 #define MPPI_PK_CSUM(COND, GETF, GETI)                                              \
@@ -510,6 +597,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             MPPI_PK_CSUM((lane & 16) != 0, (dpp_rows<kRowBcast15, 0xA>), (dpp_rows_i<kRowBcast15, 0xA>))
             MPPI_PK_CSUM((lane & 32) != 0, (dpp_rows<kRowBcast31, 0xC>), (dpp_rows_i<kRowBcast31, 0xC>))
 #undef MPPI_PK_CSUM
+#endif
             float cex = dpp<kWaveShr1>(cz);               // what the lanes before me hold of j0
             if (starts0) cex = 0.0f;
             const float tot_h = cex + cA;                 // complete where trajectory j0 ends
