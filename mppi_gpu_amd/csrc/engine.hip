@@ -289,9 +289,19 @@ int ensure_geometry(mppi_engine_t* e)
         const int per_cu = strict ? 0
                            : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need)
                                     : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
+        // The occupancy query resolves the very instantiation this geometry launches (the rollout
+        // units are translation units of their own): if it fails, the kernel is not in the loaded
+        // code object and the launch would abort() inside the HIP runtime -- an error code instead.
+        if (!strict && per_cu <= 0) {
+            (void)hipGetLastError();
+            return fail(MPPI_ENODEV, "the %s rollout kernel for act_dim %d, %d groups per lane (%s "
+                        "noise) cannot be resolved in the loaded gfx950 code object",
+                        packed ? "packed" : "row-aligned", e->A, NGt,
+                        in_kernel_sampling ? "sampled" : "injected");
+        }
         // (the packed kernel's blocks meet only once, at their end: one round of resident blocks
         //  walking all tiles is best, measured 81 us at 512 blocks against 87 at 1536, C3)
-        max_blocks = per_cu > 0 ? (packed ? 1 : 3) * per_cu * ncu : 2048;
+        max_blocks = strict ? 2048 : (packed ? 1 : 3) * per_cu * ncu;
         if (max_blocks > 3072) max_blocks = 3072;
     }
     {   // what the chip holds AT ONCE of the riding variant of this kernel (its blocks wait for each
@@ -305,6 +315,12 @@ int ensure_geometry(mppi_engine_t* e)
         const int per_cu_ride = strict ? 0
             : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need, true)
                      : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need, true);
+        if (!strict && per_cu_ride <= 0) {
+            (void)hipGetLastError();
+            return fail(MPPI_ENODEV, "the riding variant of the %s rollout kernel (act_dim %d, %d "
+                        "groups per lane) cannot be resolved in the loaded gfx950 code object",
+                        packed ? "packed" : "row-aligned", e->A, NGt);
+        }
         e->resident_ride = (long long)per_cu_ride * ncu;
     }
     if (max_blocks > mppi::kMaxParts) max_blocks = mppi::kMaxParts;
@@ -1115,8 +1131,13 @@ int mppi_set_noise(mppi_engine* e, const float* noise)
         int rc_ = settle(e);
         if (rc_) return rc_;
     }
+    // The sampling and the injected-noise instantiations of a kernel differ in registers, hence in
+    // the blocks a CU holds: the persistent grid and -- what the riding combine's co-residency test
+    // leans on -- `resident_ride` belong to ONE of them.  A change of mode re-plans the launch.
+    const bool was = e->injected;
     if (!noise) {
         e->injected = false;
+        if (was) e->geom_ok = false;
         return MPPI_OK;
     }
     const size_t n = (size_t)e->K * e->T * e->A;
@@ -1124,6 +1145,7 @@ int mppi_set_noise(mppi_engine* e, const float* noise)
     HIPCHK(hipMemcpy(e->d_Einj, noise, n * sizeof(float), hipMemcpyHostToDevice));
     e->injected = true;
     e->inj_dirty = true;
+    if (!was) e->geom_ok = false;
     return MPPI_OK;
 }
 
