@@ -8,8 +8,17 @@
 //   mppi_closed_loop [-c config.yaml] [-k key] [--dims A] [--samples K] [--horizon T] [--dt 0.1]
 //                    [--model file.xml] [--seconds S] [-t|--traj-save out.csv] [-s|--step-save prefix]
 //                    [--lambda L] [--noise SIGMA] [--max-a config|LIMIT]
+//                    [--gpus N [--transport collective|direct|copy]]
+// --gpus N (N >= 1, or `all`) runs the controller over N GPUs of this process through
+// ShardedPointMassModel (include/point_mass_sharded.hpp): one shard engine and host thread per
+// device, the per-solve exchange by RCCL all-gather (default), peer stores or peer copies.  Without
+// it the single-GPU PointMassModel is used, as in the reference (src/main.cu:311).
+//                    [--use-config-params]
 // -c reads a configuration file with the reference's keys (include/mppi_config.hpp); options
 // given after it override single values (the reference's -c/--config, src/main.cu:401-453).
+// Like the reference, the file's `lambda` and `init-act` are parsed and NOT applied (its controller
+// runs with lambda 1 and zero initial controls whatever the file says);
+// --use-config-params applies them.
 // -k/--key (the reference's MuJoCo licence file, src/main.cu:417-423) is accepted and ignored: the
 // stand-in plant needs no key.  --max-a switches the action limit ON (the reference parses max-a,
 // src/main.cu:524,566-568, and never applies it, so the default is off): `config` takes the
@@ -17,6 +26,7 @@
 #include "mppi_config.hpp"
 #include "mppi_env.hpp"
 #include "point_mass.hpp"
+#include "point_mass_sharded.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -92,16 +102,22 @@ int main(int argc, char** argv)
     double seconds = 2.0;
     std::string model, traj, step_prefix;
     std::vector<float> cfg_goal, cfg_w, cfg_init, cfg_max_a;
-    std::string max_a_opt;
-    for (int i = 1; i + 1 < argc; i += 2) {
-        std::string k = argv[i], v = argv[i + 1];
+    std::string max_a_opt, transport = "collective";
+    int gpus = -1;              // -1: single-GPU PointMassModel; 0: all visible; n: n shards
+    bool use_cfg_params = false, lambda_given = false;
+    float cfg_lambda = 0.f;
+    for (int i = 1; i < argc; i += 2) {
+        std::string k = argv[i];
+        if (k == "--use-config-params") { use_cfg_params = true; --i; continue; }   // a flag: no value
+        if (i + 1 >= argc) { fprintf(stderr, "option %s needs a value\n", k.c_str()); return 2; }
+        std::string v = argv[i + 1];
         if (k == "-c" || k == "--config") {
             MppiConfig cfg;
             if (!cfg.parse_file(v) || !cfg.consistent()) {
                 fprintf(stderr, "config error: %s\n", cfg.error.c_str());
                 return 1;
             }
-            A = cfg.act_dim; K = cfg.samples; T = cfg.horizon; dt = cfg.dt; lambda = cfg.lambda;
+            A = cfg.act_dim; K = cfg.samples; T = cfg.horizon; dt = cfg.dt; cfg_lambda = cfg.lambda;
             // the shipped files carry noise 0.25 while the reference's effective sigma is its
             // hard-coded 0.025; --noise overrides explicitly
             cfg_goal = cfg.goal; cfg_w = cfg.cost_w; cfg_init = cfg.init_act; cfg_max_a = cfg.max_a;
@@ -116,10 +132,17 @@ int main(int argc, char** argv)
         else if (k == "--seconds") seconds = atof(v.c_str());
         else if (k == "--traj" || k == "--traj-save" || k == "-t") traj = v;
         else if (k == "--step-save" || k == "-s") step_prefix = v;
-        else if (k == "--lambda") lambda = (float)atof(v.c_str());
+        else if (k == "--lambda") { lambda = (float)atof(v.c_str()); lambda_given = true; }
         else if (k == "--noise") sigma = (float)atof(v.c_str());
+        else if (k == "--gpus") gpus = (v == "all") ? 0 : atoi(v.c_str());
+        else if (k == "--transport") transport = v;
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
+    // The reference parses `lambda` and `init-act` and never hands them to its controller (effective
+    // values 1 and 0: src/main.cu:311, src/point_mass.cu:53-54, src/main.cu:678-684):
+    // they are applied only on request.  --lambda on the command line always counts.
+    if (use_cfg_params && cfg_lambda > 0.f && !lambda_given) lambda = cfg_lambda;
+    if (!use_cfg_params) cfg_init.clear();
     if (A < 1 || A > 4) { fprintf(stderr, "--dims must be 1..4, got %d\n", A); return 2; }
     if (K < 1 || T < 1) { fprintf(stderr, "--samples and --horizon must be >= 1\n"); return 2; }
     const int S = 2 * A;
@@ -135,54 +158,75 @@ int main(int argc, char** argv)
     std::cout << env << std::endl;
     if (env.dims() != A) { fprintf(stderr, "model has %d axes, --dims %d\n", env.dims(), A); return 2; }
 
-    PointMassModel* model_ctl = new PointMassModel(K, T, dt, S, A, false);
-    std::vector<float> sig(A, sigma);
-    model_ctl->set_params(lambda, sig.data(), nullptr);
-    if (!max_a_opt.empty()) {
-        std::vector<float> lim(A, (float)atof(max_a_opt.c_str()));
-        if (max_a_opt == "config") {
-            if ((int)cfg_max_a.size() != A) { fprintf(stderr, "--max-a config needs -c with max-a\n"); return 2; }
-            lim = cfg_max_a;
-        }
-        model_ctl->set_action_limit(lim.data());
-        printf("action limit on:");
-        for (float v : lim) printf(" %g", v);
-        printf("\n");
-    }
-    std::vector<float> x(S), U(T * A, 0.0f), next_act(A), u_prev(T * A);
-    if (!cfg_init.empty())          // reference init_action_seq, src/main.cu:678-684
-        for (int t = 0; t < T; ++t)
-            for (int a = 0; a < A; ++a) U[t * A + a] = cfg_init[a];
-    env.get_x(x.data());
-    model_ctl->memcpy_set_data(x.data(), U.data(), goal.data(), w.data());
-
-    std::vector<std::vector<float>> xs{x}, us;
+    printf("controller parameters: lambda %g sigma %g init-act %s\n", lambda, sigma,
+           cfg_init.empty() ? "zero" : "from config");
+    fflush(stdout);
+    std::vector<float> x(S);
     double ctl_ms = 0.0, worst_ms = 0.0;
     size_t t = 0;
-    bool done = false;
-    while (!done) {
-        model_ctl->get_u(u_prev.data());
-        auto t1 = std::chrono::steady_clock::now();
-        model_ctl->get_act(next_act.data());
-        auto t2 = std::chrono::steady_clock::now();
-        const double ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-        ctl_ms += ms;
-        if (t > 0 && ms > worst_ms) worst_ms = ms;      // first call includes one-off set-up
-        done = env.simulate(next_act.data());
-        env.get_x(x.data());
-        us.push_back(next_act);
-        xs.push_back(x);
-        if (!step_prefix.empty()) {          // reference src/main.cu:355-366 (save_step)
-            std::vector<float> hx((size_t)K * (T + 1) * S), hu((size_t)T * A), he((size_t)K * T * A),
-                hc(K), hw(K);
-            float beta = 0, nabla = 0;
-            model_ctl->get_inf(hx.data(), hu.data(), he.data(), hc.data(), &beta, &nabla, hw.data());
-            to_csv_step(step_prefix + std::to_string(t), hx.data(), hu.data(), u_prev.data(),
-                        he.data(), hc.data(), hw.data(), K, T, S, A);
+    std::vector<std::vector<float>> xs, us;
+    auto drive = [&](auto* model_ctl) -> int {
+        std::vector<float> sig(A, sigma);
+        model_ctl->set_params(lambda, sig.data(), nullptr);
+        if (!max_a_opt.empty()) {
+            std::vector<float> lim(A, (float)atof(max_a_opt.c_str()));
+            if (max_a_opt == "config") {
+                if ((int)cfg_max_a.size() != A) { fprintf(stderr, "--max-a config needs -c with max-a\n"); return 2; }
+                lim = cfg_max_a;
+            }
+            model_ctl->set_action_limit(lim.data());
+            printf("action limit on:");
+            for (float v : lim) printf(" %g", v);
+            printf("\n");
         }
-        model_ctl->set_x(x.data());
-        ++t;
+        std::vector<float> U(T * A, 0.0f), next_act(A), u_prev(T * A);
+        if (!cfg_init.empty())          // reference init_action_seq, src/main.cu:678-684
+            for (int t = 0; t < T; ++t)
+                for (int a = 0; a < A; ++a) U[t * A + a] = cfg_init[a];
+        env.get_x(x.data());
+        model_ctl->memcpy_set_data(x.data(), U.data(), goal.data(), w.data());
+
+        xs.push_back(x);
+        bool done = false;
+        while (!done) {
+            model_ctl->get_u(u_prev.data());
+            auto t1 = std::chrono::steady_clock::now();
+            model_ctl->get_act(next_act.data());
+            auto t2 = std::chrono::steady_clock::now();
+            const double ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+            ctl_ms += ms;
+            if (t > 0 && ms > worst_ms) worst_ms = ms;      // first call includes one-off set-up
+            done = env.simulate(next_act.data());
+            env.get_x(x.data());
+            us.push_back(next_act);
+            xs.push_back(x);
+            if (!step_prefix.empty()) {          // reference src/main.cu:355-366 (save_step)
+                std::vector<float> hx((size_t)K * (T + 1) * S), hu((size_t)T * A), he((size_t)K * T * A),
+                    hc(K), hw(K);
+                float beta = 0, nabla = 0;
+                model_ctl->get_inf(hx.data(), hu.data(), he.data(), hc.data(), &beta, &nabla, hw.data());
+                to_csv_step(step_prefix + std::to_string(t), hx.data(), hu.data(), u_prev.data(),
+                            he.data(), hc.data(), hw.data(), K, T, S, A);
+            }
+            model_ctl->set_x(x.data());
+            ++t;
+        }
+        return 0;
+    };
+    int rc_drive;
+    if (gpus >= 0) {
+        if (transport != "collective" && transport != "direct" && transport != "copy") {
+            fprintf(stderr, "--transport must be collective, direct or copy\n");
+            return 2;
+        }
+        ShardedPointMassModel ctl(K, T, dt, S, A, false, gpus, transport.c_str());
+        printf("controller: %d shard(s), transport %s\n", ctl.n_shards(), ctl.transport());
+        rc_drive = drive(&ctl);
+    } else {
+        PointMassModel ctl(K, T, dt, S, A, false);
+        rc_drive = drive(&ctl);
     }
+    if (rc_drive) return rc_drive;
     double dist = 0;
     for (int i = 0; i < A; ++i) dist += (x[i] - goal[i]) * (x[i] - goal[i]);
     std::cout << "Average controller execution time: " << ctl_ms / t << std::endl;
@@ -191,6 +235,5 @@ int main(int argc, char** argv)
     printf("RESULT steps=%zu avg_ms=%.4f worst_ms=%.4f final_dist=%.4f budget_ms=10\n", t,
            ctl_ms / t, worst_ms, std::sqrt(dist));
     if (!traj.empty()) to_csv_traj(traj, xs, us, A);
-    delete model_ctl;
     return 0;
 }

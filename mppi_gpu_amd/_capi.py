@@ -71,7 +71,36 @@ SIGNATURES = {
     "mppi_version": (C.c_char_p, []),
 }
 
+# include/mppi_gpu_amd_sharded.h (libmppi_gpu_amd_sharded.so: the single-process multi-GPU host)
+sharded_p = C.c_void_p
+SHARDED_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmppi_gpu_amd_sharded.so")
+SHARDED_SIGNATURES = {
+    "mppi_sharded_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      c_int_p, C.c_int, C.POINTER(sharded_p)]),
+    "mppi_sharded_destroy": (None, [sharded_p]),
+    "mppi_sharded_set_data": (C.c_int, [sharded_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "mppi_sharded_set_x": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_get_x": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_get_u": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_get_act": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_solve_async": (C.c_int, [sharded_p]),
+    "mppi_sharded_sync_act": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_get_inf": (C.c_int, [sharded_p] + [c_float_p] * 7),
+    "mppi_sharded_get_data": (C.c_int, [sharded_p, c_float_p, c_float_p]),
+    "mppi_sharded_set_params": (C.c_int, [sharded_p, C.c_float, c_float_p, c_float_p]),
+    "mppi_sharded_set_seed": (C.c_int, [sharded_p, C.c_ulonglong]),
+    "mppi_sharded_set_noise": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_set_action_limit": (C.c_int, [sharded_p, c_float_p]),
+    "mppi_sharded_set_timeout": (C.c_int, [sharded_p, C.c_double]),
+    "mppi_sharded_n_shards": (C.c_int, [sharded_p]),
+    "mppi_sharded_transport": (C.c_int, [sharded_p]),
+    "mppi_sharded_shard_info": (C.c_int, [sharded_p, C.c_int, C.POINTER(C.c_longlong)]),
+    "mppi_sharded_engine": (engine_p, [sharded_p, C.c_int]),
+    "mppi_sharded_last_error": (C.c_char_p, []),
+}
+
 _lib = None
+_slib = None
 
 
 def load():
@@ -98,6 +127,23 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    return lib
+
+
+def load_sharded():
+    """The single-process multi-GPU host library (links libmppi_gpu_amd.so and librccl)."""
+    global _slib
+    if _slib is not None:
+        return _slib
+    load()      # torch (its HIP runtime and RCCL) first, then the engine library
+    if not os.path.exists(SHARDED_LIB_PATH):
+        raise ImportError(f"{SHARDED_LIB_PATH} is missing: build it with `make -C mppi_gpu_amd/csrc`")
+    lib = C.CDLL(SHARDED_LIB_PATH)
+    for name, (res, args) in SHARDED_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _slib = lib
     return lib
 
 

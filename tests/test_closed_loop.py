@@ -14,7 +14,8 @@ LIBDIR = os.path.join(ROOT, "mppi_gpu_amd", "lib")
 
 def _cc(src, exe):
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", INC, src, "-o", exe, "-L", LIBDIR,
-                        "-lmppi_gpu_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"],
+                        "-lmppi_gpu_amd_sharded", "-lmppi_gpu_amd", f"-Wl,-rpath,{LIBDIR}",
+                        "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -104,6 +105,27 @@ def test_driver_rejects_bad_dims_before_touching_anything(tmp_path):
         assert out.returncode == 2 and "--dims must be 1..4" in out.stderr
     out = subprocess.run([exe, "--frobnicate", "1"], capture_output=True, text=True)
     assert out.returncode == 2 and "unknown option" in out.stderr
+
+
+def test_config_lambda_and_init_act_are_opt_in(tmp_path):
+    """the reference parses `lambda` and `init-act` (src/main.cu:524,566-568) and never
+    hands them to its controller (src/main.cu:311; lambda 1, src/point_mass.cu:53-54; U0 = 0,
+    src/main.cu:678-684).  -c alone therefore leaves both at the reference's effective values;
+    --use-config-params applies the file's; --lambda on the command line always counts.  (The
+    parameter line is printed before the controller is created: no GPU needed.)"""
+    from test_config import TEST_YAML
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    cfg = tmp_path / "mppi-config-test.yaml"
+    cfg.write_text(TEST_YAML)                     # lambda: 1.5, init-act: [0.1, 0.2]
+
+    def line(*extra):
+        out = subprocess.run([exe, "-c", str(cfg), "--seconds", "0.02", *extra],
+                             capture_output=True, text=True).stdout
+        return re.search(r"controller parameters: (.*)", out).group(1)
+    assert line() == "lambda 1 sigma 0.025 init-act zero"
+    assert line("--use-config-params") == "lambda 1.5 sigma 0.025 init-act from config"
+    assert line("--lambda", "3") == "lambda 3 sigma 0.025 init-act zero"
+    assert line("--use-config-params", "--lambda", "3") == "lambda 3 sigma 0.025 init-act from config"
 
 
 @pytest.mark.gpu

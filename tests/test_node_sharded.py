@@ -1,0 +1,249 @@
+"""The single-process multi-GPU host (include/mppi_gpu_amd_sharded.h, include/point_mass_sharded.hpp,
+libmppi_gpu_amd_sharded.so): one shard engine + host worker thread per GPU, exchange by native
+RCCL all-gather (default), in-kernel peer stores, or peer copies.
+
+CPU tests: header / binding / library agree, the library really links librccl, a host written
+against the class builds with plain g++, no GPU = loud failure.
+GPU tests (one-GPU box): 2 and 3 shard engines placed on the SAME device through the `direct` and
+`copy` transports must give identical bits to each other and to the torch-free gather+finish path,
+agree with the single engine to rounding (another partition of the sums), and not depend on the
+number of shards in their NOISE at all; one shard through RCCL (`collective`: ncclCommInitAll +
+ncclAllGather with one rank) must reproduce the single engine bit for bit."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "mppi_gpu_amd_sharded.h")
+LIBDIR = os.path.join(ROOT, "mppi_gpu_amd", "lib")
+SRC = os.path.join(ROOT, "tests", "cpp", "host_loop_sharded.cpp")
+EXE = os.path.join(ROOT, "tests", "cpp", "host_loop_sharded")
+SIGMA = 0.025
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mppi_sharded_[a-z_0-9]+)\s*\(", txt)))
+
+
+def _build():
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), SRC, "-o", EXE, "-L", LIBDIR,
+           "-lmppi_gpu_amd_sharded", "-lmppi_gpu_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return EXE
+
+
+def test_header_binding_and_library_agree():
+    from mppi_gpu_amd import _capi
+    assert _declared() == sorted(_capi.SHARDED_SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.SHARDED_LIB_PATH], check=True,
+                         capture_output=True, text=True).stdout
+    assert set(_declared()) <= set(re.findall(r" T (mppi_sharded_[a-z_0-9]+)", out))
+    _capi.load_sharded()
+
+
+def test_library_links_rccl_natively_and_not_the_oracle():
+    from mppi_gpu_amd import _capi
+    out = subprocess.run(["ldd", _capi.SHARDED_LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "librccl.so" in out and "libmppi_gpu_amd.so" in out and "oracle" not in out
+    und = subprocess.run(["nm", "-D", "--undefined-only", _capi.SHARDED_LIB_PATH], check=True,
+                         capture_output=True, text=True).stdout
+    for sym in ("ncclCommInitAll", "ncclAllGather", "ncclCommDestroy", "mppi_create_shard",
+                "mppi_solve_local_async", "mppi_solve_finish_async", "mppi_solve_exchange_async",
+                "hipDeviceEnablePeerAccess", "hipMemcpyPeerAsync"):
+        assert sym in und, sym
+    # and the single-GPU library stays free of RCCL
+    assert "rccl" not in subprocess.run(["ldd", _capi.LIB_PATH], check=True, capture_output=True,
+                                        text=True).stdout
+
+
+def test_cpp_host_builds_with_gpp_and_exports_the_class():
+    _build()
+    syms = subprocess.run(["nm", "-D", "-C", os.path.join(LIBDIR, "libmppi_gpu_amd_sharded.so")],
+                          capture_output=True, text=True, check=True).stdout
+    for member in ("ShardedPointMassModel::ShardedPointMassModel(int, int, float, int, int, bool, int, char const*, int const*)",
+                   "ShardedPointMassModel::get_act(float*)",
+                   "ShardedPointMassModel::memcpy_set_data(float*, float*, float*, float*)",
+                   "ShardedPointMassModel::get_x(float*)", "ShardedPointMassModel::set_x(float*)",
+                   "ShardedPointMassModel::get_u(float*)",
+                   "ShardedPointMassModel::memcpy_get_data(float*, float*)",
+                   "ShardedPointMassModel::get_inf(float*, float*, float*, float*, float*, float*, float*)"):
+        assert member in syms, member
+
+
+def test_no_gpu_or_bad_arguments_fail_loudly():
+    from mppi_gpu_amd import _capi, MppiError
+    from mppi_gpu_amd.node import NodePointMassModel
+    if _capi.load().mppi_device_count() > 0:
+        with pytest.raises(MppiError) as ei:
+            NodePointMassModel(100, 10, 0.1, 4, 2, devices=[0, 0], transport="collective")
+        assert "RCCL cannot place two ranks on one device" in str(ei.value)
+        with pytest.raises(MppiError):
+            NodePointMassModel(2, 10, 0.1, 4, 2, devices=[0, 0, 0], transport="copy")   # K < shards
+        return
+    with pytest.raises(MppiError) as ei:
+        NodePointMassModel(100, 10, 0.1, 4, 2)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+# ---------------------------------------------------------------------------------------------------
+
+def _single(A, K, T, c, seed, n_solves, lam=1.0):
+    from mppi_gpu_amd import PointMassModel
+    with PointMassModel(K, T, float(c["dt"]), 2 * A, A) as m:
+        m.set_seed(seed)
+        m.set_params(lam)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        acts = [m.get_act() for _ in range(n_solves)]
+        inf = m.get_inf(x=False)
+    return acts, inf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A,K,T,lam", [(2, 6000, 120, 1.0), (3, 9001, 200, 150.0)])
+def test_shards_on_one_device_agree_bitwise_across_transports(gpu, A, K, T, lam):
+    from mppi_gpu_amd.node import NodePointMassModel
+    c = ol.make_case(A, 1, T, seed=61, u_scale=0.03)
+    n_solves = 4
+    acts1, inf1 = _single(A, K, T, c, 9, n_solves, lam)
+    scale = max(float(np.abs(inf1["u"]).max()), SIGMA)
+    got = {}
+    for n, transport in ((2, "copy"), (2, "direct"), (3, "copy"), (3, "direct")):
+        with NodePointMassModel(K, T, float(c["dt"]), 2 * A, A, devices=[0] * n,
+                                transport=transport) as m:
+            assert m.n_shards == n and m.transport == transport
+            rng = [m.shard_info(i) for i in range(n)]
+            assert rng[0]["k_begin"] == 0 and rng[-1]["k_end"] == K
+            assert all(rng[i]["k_end"] == rng[i + 1]["k_begin"] for i in range(n - 1))
+            m.set_seed(9)
+            m.set_params(lam)
+            m.set_timeout(3.0)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            acts = [m.get_act() for _ in range(n_solves)]
+            inf = m.get_inf(x=False)
+        got[(n, transport)] = (acts, inf)
+        # the noise does not depend on the sharding at all; the controls agree to rounding
+        assert np.array_equal(inf["e"], inf1["e"]), (n, transport)
+        # (a shard of K/n samples may run another lanes-per-trajectory geometry: costs to rounding)
+        np.testing.assert_allclose(inf["cost"], inf1["cost"], rtol=3e-6, atol=0)
+        # (chains of n_solves sampled solves at lambda 1 are nearly one-hot: see test_gpu_parity's
+        #  docstring for the bar of such cases; the lambda = 150 case holds the plain one)
+        bar = 1e-5 * scale if lam > 10 else n_solves * max(
+            1e-5 * scale, 4 * float(np.spacing(np.float32(inf1["cost"].max()))) / lam * 4.5 * SIGMA)
+        for a, b in zip(acts, acts1):
+            assert np.abs(a - b).max() <= bar, (n, transport)
+        assert np.abs(inf["u"] - inf1["u"]).max() <= bar
+        ulp_c = float(np.spacing(np.float32(inf1["cost"].max()))) / lam
+        np.testing.assert_allclose(inf["weight"], inf1["weight"], rtol=max(1e-4, 16 * ulp_c), atol=1e-12)
+        assert abs(inf["weight"].astype(np.float64).sum() - 1.0) < 2e-5
+    for n in (2, 3):       # same shards, another transport: the same bits
+        (a_c, i_c), (a_d, i_d) = got[(n, "copy")], got[(n, "direct")]
+        for x, y in zip(a_c, a_d):
+            assert np.array_equal(x, y), n
+        assert np.array_equal(i_c["u"], i_d["u"]) and i_c["nabla"] == i_d["nabla"]
+
+
+@pytest.mark.gpu
+def test_one_shard_through_rccl_equals_the_single_engine(gpu):
+    """transport "collective" with one rank: ncclCommInitAll + ncclAllGather called natively from
+    the worker thread; one partial combined with factor exp(0) = 1 is the single engine's update."""
+    from mppi_gpu_amd.node import NodePointMassModel
+    A, K, T = 3, 5000, 200
+    c = ol.make_case(A, 1, T, seed=62, u_scale=0.03)
+    acts1, inf1 = _single(A, K, T, c, 4, 3)
+    with NodePointMassModel(K, T, float(c["dt"]), 2 * A, A, n_shards=1, transport="collective") as m:
+        m.set_seed(4)
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        acts = [m.get_act() for _ in range(3)]
+        inf = m.get_inf(x=False)
+        assert m.transport == "collective" and m.n_shards == 1
+    for a, b in zip(acts, acts1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(inf["u"], inf1["u"]) and np.array_equal(inf["e"], inf1["e"])
+
+
+@pytest.mark.gpu
+def test_back_to_back_solves_and_injected_noise_parity(gpu):
+    """solve_async x n then sync (DIRECT: every exchange rides in the next rollout launch) equals n
+    blocking get_act calls; on injected noise the sharded solve meets the oracle at the plain bar."""
+    from mppi_gpu_amd.node import NodePointMassModel
+    A, K, T = 2, 6000, 100
+    c = ol.make_case(A, K, T, seed=63)
+    ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=60.0)
+    scale = max(float(np.abs(ref["U"]).max()), SIGMA)
+    for transport in ("direct", "copy"):
+        with NodePointMassModel(K, T, float(c["dt"]), 2 * A, A, devices=[0, 0], transport=transport) as m:
+            m.set_params(60.0)
+            m.set_timeout(3.0)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf(x=False, e=False)
+            assert np.abs(inf["u"] - ref["U"]).max() <= 1e-5 * scale
+            assert np.abs(act - ref["next_act"]).max() <= 1e-5 * scale
+            np.testing.assert_allclose(inf["weight"], ref["weights"], rtol=1e-4, atol=1e-12)
+            np.testing.assert_allclose(inf["nabla"], ref["nabla"], rtol=1e-5)
+            # sampling mode, chains
+            m.set_noise(None)
+            m.set_seed(3)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            blocking = [m.get_act() for _ in range(5)][-1]
+            u_block = m.get_u()
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            for _ in range(5):
+                m.solve_async()
+            free = m.sync_act()
+            assert np.array_equal(free, blocking) and np.array_equal(m.get_u(), u_block), transport
+            if transport == "direct":
+                assert m.engine_launch_counts(0)["riding"] >= 1
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_host_loop_equals_python_driven_run(gpu):
+    from mppi_gpu_amd.node import NodePointMassModel
+    exe = _build()
+    K, T, iters = 3000, 50, 6
+    outs = {}
+    for shards, transport, same in ((1, "collective", 0), (2, "copy", 1), (2, "direct", 1)):
+        out = subprocess.run([exe, str(K), str(T), str(iters), str(shards), transport, str(same)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr + out.stdout
+        assert f"SHARDS {shards} {transport}" in out.stdout
+        acts = np.array([[float(a), float(b)] for a, b in re.findall(r"ACT \d+ (\S+) (\S+)", out.stdout)],
+                        np.float32)
+        assert acts.shape == (iters, 2)
+        outs[(shards, transport)] = acts
+    assert np.array_equal(outs[(2, "copy")], outs[(2, "direct")])
+    x = np.zeros(4, np.float32)
+    dt = np.float32(0.1)
+    with NodePointMassModel(K, T, 0.1, 4, 2, devices=[0, 0], transport="copy") as m:
+        m.set_seed(11)
+        m.memcpy_set_data(x, np.zeros((T, 2), np.float32), [1, 0, 0, 0], [1, 1, 50, 50])
+        for it in range(iters):
+            a = m.get_act()
+            assert np.array_equal(a, outs[(2, "copy")][it]), it
+            for i in range(2):
+                p = x[i] + dt * x[i + 2] + np.float32(0.5) * dt * dt * a[i]
+                v = x[i + 2] + dt * a[i]
+                x[i], x[i + 2] = p, v
+            m.set_x(x)
+
+
+@pytest.mark.gpu
+def test_closed_loop_app_runs_over_the_sharded_controller(gpu, tmp_path):
+    from test_closed_loop import _cc
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    out = subprocess.run([exe, "--dims", "3", "--samples", "20000", "--horizon", "200", "--seconds", "0.3",
+                          "--gpus", "all", "--transport", "collective"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "transport collective" in out.stdout
+    m = re.search(r"RESULT steps=(\d+) avg_ms=(\S+) worst_ms=(\S+)", out.stdout)
+    assert m and int(m.group(1)) >= 10 and float(m.group(3)) < 10.0, out.stdout
