@@ -234,21 +234,22 @@ int ensure_geometry(mppi_engine_t* e)
     if (!strict && e->user_packing >= 0 && (e->user_chunks == 0 || e->user_packing > 0)) {
         bool w_ok = true;
         for (int i = 0; i < e->S; ++i) w_ok = w_ok && e->w[i] >= 0.f;
-        const bool whole = e->T % e->SG == 0;
         double best = 0.0;
         for (const int* cand = mppi::packed_ng_list(e->A); *cand; ++cand) {
             const int n = *cand;
             if (e->user_packing > 0 && n != e->user_packing) continue;
-            if (!whole || !w_ok || NGT < n || NGT > 64 * n) continue;
+            if (!w_ok || NGT < n || NGT > 64 * n) continue;
             const int tpw = 64 * n / NGT;
-            const double util = (double)tpw * NGT / (64.0 * n);
+            // useful fraction of the group slots (a ragged last group counts its real steps)
+            const double util = (double)tpw * ((double)e->T / e->SG) / (64.0 * n);
             if (util > best + 1e-9) { best = util; pk_NG = n; TPW = tpw; }
         }
         if (e->user_packing > 0 && !pk_NG)
             return fail(MPPI_EINVAL, "packed kernel with %d groups per lane not available for "
-                        "T=%d act_dim=%d (needs T %% %d == 0, weights >= 0, an instantiated size)",
-                        e->user_packing, e->T, e->A, e->SG);
-        const double util_row = (double)NGT / ((double)C * ng);
+                        "T=%d act_dim=%d (needs weights >= 0, an instantiated size, and %d <= "
+                        "ceil(T / %d) <= 64 x that size)",
+                        e->user_packing, e->T, e->A, e->user_packing, e->SG);
+        const double util_row = ((double)e->T / e->SG) / ((double)C * ng);
         packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
         // Packing buys throughput: fewer, fuller tiles.  A launch so short that no block would walk
         // a second tile (K = 1e4, 2-D: 500 tile groups) is a latency problem instead, and there
@@ -256,7 +257,7 @@ int ensure_geometry(mppi_engine_t* e)
         if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
             packed = false;
         if (packed && e->user_packing <= 0 &&
-            mppi::packed_lds_bytes(e->A, pk_NG, e->NBT, TPW) > 64 * 1024)
+            mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) > 64 * 1024)
             packed = false;          // horizon too long for the LDS slots: row-aligned kernel
     }
     if (packed) {
@@ -268,12 +269,14 @@ int ensure_geometry(mppi_engine_t* e)
     const int L = ng * e->SG;
     const int c_last = (e->T - 1) / L;
     const int n_last = e->T - c_last * L;
-    const int NBTp = packed ? e->NBT : ((C * nq > e->NBT) ? C * nq : e->NBT);
+    // blocks of the controls staged in LDS: the packed kernel pads a ragged horizon to whole groups
+    const int NBTp = packed ? NGT * e->BPG : ((C * nq > e->NBT) ? C * nq : e->NBT);
     const long long lanes = (long long)e->K * C;
     const long long ntb = packed ? (((long long)e->K + TPW - 1) / TPW + 3) / 4
                                  : (lanes + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
     if (ntb > 0x7fffffffLL) return fail(MPPI_EINVAL, "too many samples");
-    const size_t lds_need = packed ? mppi::packed_lds_bytes(e->A, pk_NG, e->NBT, TPW)
+    const bool ragged = e->T % e->SG != 0;     // (packed kernel: the RAGGED instantiations)
+    const size_t lds_need = packed ? mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW)
                                    : mppi::rollout_lds_bytes(NBTp, C * nq * 4);
     int max_blocks = e->user_max_blocks;
     if (max_blocks <= 0) {
@@ -287,7 +290,7 @@ int ensure_geometry(mppi_engine_t* e)
             ncu = prop.multiProcessorCount;
         const bool in_kernel_sampling = !e->injected;
         const int per_cu = strict ? 0
-                           : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need)
+                           : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need, false, ragged)
                                     : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need);
         // The occupancy query resolves the very instantiation this geometry launches (the rollout
         // units are translation units of their own): if it fails, the kernel is not in the loaded
@@ -313,7 +316,7 @@ int ensure_geometry(mppi_engine_t* e)
             ncu = prop.multiProcessorCount;
         const bool in_kernel_sampling = !e->injected;
         const int per_cu_ride = strict ? 0
-            : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need, true)
+            : packed ? mppi::packed_blocks_per_cu(e->A, pk_NG, in_kernel_sampling, lds_need, true, ragged)
                      : mppi::rollout_blocks_per_cu(e->A, NGt, in_kernel_sampling, lds_need, true);
         if (!strict && per_cu_ride <= 0) {
             (void)hipGetLastError();
@@ -349,7 +352,7 @@ int ensure_geometry(mppi_engine_t* e)
         e->d_pm = e->d_ps = e->d_pN = nullptr;
         HIPCHK(hipMalloc(&e->d_pm, (size_t)grid * sizeof(float)));
         HIPCHK(hipMalloc(&e->d_ps, (size_t)grid * sizeof(float)));
-        HIPCHK(hipMalloc(&e->d_pN, (size_t)grid * e->TA * sizeof(float)));
+        HIPCHK(hipMalloc(&e->d_pN, (size_t)grid * e->NBT * 4 * sizeof(float)));
         e->part_cap = grid;
     }
     e->C = C;
@@ -427,6 +430,8 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.packed = e->packed ? 1 : 0;
     a.NGT = e->NGT;
     a.TPW = e->TPW;
+    a.pk_nlast = e->T - (e->NGT - 1) * e->SG;
+    a.Nrow = e->NBT * 4;
     a.pk_has_cg = 0;
     a.store_e = (e->store_noise || e->strict) ? 1 : 0;   // (the strict kernel re-reads its noise)
     for (int i = 0; i < e->A; ++i) {
@@ -503,7 +508,7 @@ void fill_own_combine(mppi_engine_t* e, mppi::CombineArgs& ca, unsigned long lon
     memset(&ca, 0, sizeof ca);
     ca.dev = e->d_state;
     ca.m = e->d_pm; ca.s = e->d_ps; ca.N = e->d_pN;
-    ca.m_stride = 1; ca.s_stride = 1; ca.N_stride = e->TA;
+    ca.m_stride = 1; ca.s_stride = 1; ca.N_stride = e->NBT * 4;
     ca.n_parts = e->grid;
     ca.TA = e->TA;
     ca.A = e->A;
@@ -949,7 +954,7 @@ int mppi_solve_async(mppi_engine* e, void* stream)
         e->pending_idx = e->solve_idx;
         e->pending_stream = st;
     } else {
-        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 1, nullptr);
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->NBT * 4, e->grid, 1, nullptr);
         if (rc) return rc;
     }
     e->solve_idx += 1;
@@ -1263,7 +1268,7 @@ int mppi_solve_local_async(mppi_engine* e, float* d_partial, void* stream)
     int rc = enqueue_rollout(e, st);      // (flushes a pending combine first)
     if (rc) return rc;
     if (e->strict)
-        return enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 0, d_partial);
+        return enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->NBT * 4, e->grid, 0, d_partial);
     // the same 256-thread combine the direct exchange runs, so that both transports add this
     // rank's partial in the same order (equal bits)
     mppi::CombineArgs ca;
@@ -1414,7 +1419,7 @@ int mppi_solve_exchange_async(mppi_engine* e, void* stream)
         e->pending_idx = e->solve_idx;
         e->pending_stream = st;
     } else {
-        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->TA, e->grid, 2, nullptr);
+        rc = enqueue_combine(e, st, e->d_pm, e->d_ps, e->d_pN, 1, 1, e->NBT * 4, e->grid, 2, nullptr);
         if (rc) return rc;
     }
     e->xg_seq += 1;

@@ -127,7 +127,7 @@ k_rollout_stream(const RolloutArgs* __restrict__ gp, float* __restrict__ Eint,
         first = false;
         __syncthreads();
     }
-    float* Nout = g.part_N + (size_t)blockIdx.x * g.TA;
+    float* Nout = g.part_N + (size_t)blockIdx.x * g.Nrow;
     for (int n = threadIdx.x; n < g.TA; n += kRolloutThreads) Nout[n] = first ? 0.0f : nrun[n];
     if (threadIdx.x == 0) {
         g.part_m[blockIdx.x] = rs.M;
@@ -350,13 +350,13 @@ template <int A>
 hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
                            const DeferredCombine& d, hipStream_t st, LaunchTiming tm);
 template <int A>
-int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride);
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride, bool ragged);
 template <int A>
 size_t packed_lds_bytes_a(int NG, int NBT, int TPW);
 #define MPPI_PACKED_EXTERN(A_)                                                                       \
     extern template hipError_t launch_packed_a<A_>(int, bool, int, const RolloutArgs&,               \
                                                    const DeferredCombine&, hipStream_t, LaunchTiming); \
-    extern template int packed_blocks_per_cu_a<A_>(int, bool, size_t, bool);                               \
+    extern template int packed_blocks_per_cu_a<A_>(int, bool, size_t, bool, bool);                           \
     extern template size_t packed_lds_bytes_a<A_>(int, int, int);
 MPPI_PACKED_EXTERN(1)
 MPPI_PACKED_EXTERN(2)
@@ -388,13 +388,13 @@ size_t packed_lds_bytes(int A, int NG, int NBT, int TPW)
     }
 }
 
-int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride)
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride, bool ragged)
 {
     switch (A) {
-        case 1: return packed_blocks_per_cu_a<1>(NG, sample, lds, ride);
-        case 2: return packed_blocks_per_cu_a<2>(NG, sample, lds, ride);
-        case 3: return packed_blocks_per_cu_a<3>(NG, sample, lds, ride);
-        case 4: return packed_blocks_per_cu_a<4>(NG, sample, lds, ride);
+        case 1: return packed_blocks_per_cu_a<1>(NG, sample, lds, ride, ragged);
+        case 2: return packed_blocks_per_cu_a<2>(NG, sample, lds, ride, ragged);
+        case 3: return packed_blocks_per_cu_a<3>(NG, sample, lds, ride, ragged);
+        case 4: return packed_blocks_per_cu_a<4>(NG, sample, lds, ride, ragged);
         default: return 0;
     }
 }

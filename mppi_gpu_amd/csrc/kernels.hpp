@@ -15,7 +15,8 @@
 //                   so a trajectory does not have to fill a power-of-two number of lanes.
 //   cost          : [K] floats.
 //   part_m/part_s : [grid] per-block running min and exp-sum (relative to that min).
-//   part_N        : [grid][TA] per-block weighted noise sums (relative to that min).
+//   part_N        : [grid][Nrow] per-block weighted noise sums (relative to that min); Nrow = TA
+//                   rounded up to whole Philox blocks, so that every row starts 16-byte aligned.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -62,6 +63,9 @@ struct RolloutArgs {
     int packed;            // != 0: packed layout -- NG = ng groups per lane, NGT groups per
     int NGT;               //       trajectory, TPW trajectories per wavefront
     int TPW;
+    int pk_nlast;          // packed: steps of the horizon in a trajectory's LAST group (1..SG; SG when
+                           // T is a whole number of groups): the steps past T are masked
+    int Nrow;              // floats per row of part_N (TA rounded up to whole Philox blocks)
     float dt;
     float B0;              // (float)(dt*dt/2.0)
     float lambda;
@@ -102,7 +106,8 @@ struct RolloutHot {
     long long k_offset;
     int K, T, TA, NBT, NBTp;
     int logC, ng, nq, L, c_last, n_last, n_tileblk;
-    int NGT, TPW;              // packed layout only
+    int NGT, TPW, pk_nlast;    // packed layout only
+    int Nrow;
     float x0[8];
 #ifdef MPPI_TRACE      // analysis builds only (tools/trace.sh): per-block region time stamps
     unsigned long long* trace;
@@ -138,7 +143,8 @@ inline RolloutHot make_hot(const RolloutArgs& a)
     h.K = a.K; h.T = a.T; h.TA = a.TA; h.NBT = a.NBT; h.NBTp = a.NBTp;
     h.logC = a.logC; h.ng = a.ng; h.nq = a.nq; h.L = a.L;
     h.c_last = a.c_last; h.n_last = a.n_last; h.n_tileblk = a.n_tileblk;
-    h.NGT = a.NGT; h.TPW = a.TPW;
+    h.NGT = a.NGT; h.TPW = a.TPW; h.pk_nlast = a.pk_nlast;
+    h.Nrow = a.Nrow;
     for (int i = 0; i < 8; ++i) h.x0[i] = a.x0[i];
 #ifdef MPPI_TRACE
     h.trace = g_mppi_trace_buf;
@@ -269,7 +275,7 @@ struct ELayout {
 // (0-terminated), its LDS need and its launcher; grid = rollout blocks, d as for the fused kernel.
 const int* packed_ng_list(int A);
 size_t packed_lds_bytes(int A, int NG, int NBTp, int TPW);
-int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride = false);
+int packed_blocks_per_cu(int A, int NG, bool sample, size_t lds, bool ride, bool ragged);
 hipError_t launch_rollout_packed(int A, int NG, bool sample, int grid, const RolloutArgs& a,
                                  const DeferredCombine& d, hipStream_t st,
                                  LaunchTiming tm = LaunchTiming());

@@ -140,7 +140,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
 
     RunState rs{INFINITY, 0.0f};
     bool first = true;
-    float* const Nout = g.part_N + (size_t)bid * TA;     // this block's partial sums
+    float* const Nout = g.part_N + (size_t)bid * h.Nrow;     // this block's partial sums
 
     for (int tb = bid; tb < n_tileblk; tb += nblk) {
         const long long gid = (long long)tb * kRolloutThreads + threadIdx.x;

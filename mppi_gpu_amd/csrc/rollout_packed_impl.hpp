@@ -26,8 +26,14 @@
 //     d_v = sqrt(w_v)(v - g_v), whose stage cost is d_p^2 + d_v^2: 7 VALU instructions per normal
 //     instead of 11 (src/point_mass_gpu.cu:97-107 + src/cost.cu:42-55 are the same arithmetic up
 //     to rounding; the test bar of the fused kernels applies).  Scales and gains come from the host.
-// Requirements (the engine falls back to the row-aligned kernel otherwise): T a whole number of
-// groups, NG <= NGT <= 64*NG, cost weights >= 0.
+//   * a horizon that is not a whole number of groups (T = 50 at act_dim 3: 12 groups of 4 steps
+//     and one of 2 -- the reference's shipped config/point_mass3d.yaml) is padded to NGT =
+//     ceil(T / SG) groups: the noise and the controls of the steps past T are zero, and in the
+//     trajectory's last group those steps neither move the state nor add stage cost.  RAGGED is a
+//     template parameter of the KERNEL: as a run-time branch inside one kernel it cost the
+//     whole-groups instantiation 6 VGPRs and 90 spilled SGPRs.
+// Requirements (the engine falls back to the row-aligned kernel otherwise): NG <= NGT <= 64*NG,
+// cost weights >= 0.
 #pragma once
 #include "device_common.hpp"
 #include "combine_impl.hpp"
@@ -71,7 +77,7 @@ struct PackedLane {     // wave-uniform constants held in VGPRs (see LaneParams 
     float dt, B0, dt2;
 };
 
-template <int A, int NG, bool SAMPLE, bool RIDE>
+template <int A, int NG, bool SAMPLE, bool RIDE, bool RAGGED>
 __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredCombine& d)
 {
     const int bid = RIDE ? (int)blockIdx.x - d.n_blocks : (int)blockIdx.x;
@@ -83,6 +89,12 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     constexpr int L = NG * SG;                // steps per lane
 
     const int K = h.K, TA = h.TA, NBT = h.NBT, NGT = h.NGT, TPW = h.TPW;
+    // RAGGED (T not a whole number of groups): NGT*BPG >= NBT blocks of the controls are staged in
+    // LDS (zero padded), pk_nlast < SG steps of a trajectory's last group lie inside the horizon,
+    // and the rows of part_N are padded to whole blocks
+    const int NBTs = RAGGED ? h.NBTp : NBT;
+    const int pk_nlast = RAGGED ? h.pk_nlast : SG;
+    const int Nrow = RAGGED ? h.Nrow : TA;
     const int n_tileblk = h.n_tileblk;
     const long long k_offset = h.k_offset;
     const unsigned long long seed = h.seed;
@@ -90,9 +102,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const RolloutArgs& g = *h.rest;           // cold part of the descriptor (device memory)
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBT] U, one float4 per block
-    float4* uclds = ulds + NBT;                                  // [NBT] lambda*inv_s*U
-    float4* buf = uclds + NBT;                                   // [4][NQ][kRow] weighted noise sums
+    float4* ulds = reinterpret_cast<float4*>(smem_raw);          // [NBTs] U, one float4 per block
+    float4* uclds = ulds + NBTs;                                 // [NBTs] lambda*inv_s*U
+    float4* buf = uclds + NBTs;                                  // [4][NQ][kRow] weighted noise sums
     float* misc = reinterpret_cast<float*>(buf + 4 * NQ * kPkRow);   // [8]
     float* ctab = misc + 8;                                      // [4][TPW + 2] trajectory costs
 
@@ -102,7 +114,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 
     // ---- loads of the nominal controls and the cold constants (complete under the Philox work) --
     const float lambda = g.lambda, inv_lambda = g.inv_lambda;
-    if constexpr (!RIDE) stage_controls_pair<A>(g, h.U_in, lambda, ulds, uclds, NBT, TA);
+    if constexpr (!RIDE) stage_controls_pair<A>(g, h.U_in, lambda, ulds, uclds, NBTs, TA);
     PackedLane<A> P;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
@@ -135,6 +147,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
     for (int gq = 1; gq < NG; ++gq)
         if (__ballot(tail_slot && split == gq) != 0ull) split_mask |= 1u << gq;
+    // ragged horizon: group `split - 1` of a lane in which trajectory j0 ends is that trajectory's
+    // LAST group; its normals with in-group index >= pk_nlast * A lie past the horizon
+    const int last_gi = ends_head ? split - 1 : -1;
     const int flag0 = (tail_slot || starts0) ? 1 : 0;      // a trajectory starts in my range
     const int n_out = tail_slot ? L - split * SG : L;      // steps of the range handed on
     const float nh = (float)(split * SG), nt = (float)(L - split * SG);
@@ -249,6 +264,12 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
                     for (int i = 0; i < 4; ++i) e[q * 4 + i] = P.sigma[(q * 4 + i) % A] * z[i];
                 }
+                if constexpr (RAGGED) {     // zero the normals past the horizon
+                    const int thr = (gi == last_gi) ? pk_nlast * A : SG * A;
+#pragma unroll
+                    for (int idx = A; idx < SG * A; ++idx)
+                        e[gi * BPG * 4 + idx] = (idx >= thr) ? 0.0f : e[gi * BPG * 4 + idx];
+                }
                 // (one group at a time: left alone, hipcc interleaves the Philox chains of all
                 //  groups of the lane and runs out of registers; the VALU is saturated by one)
                 __builtin_amdgcn_sched_barrier(0);
@@ -278,7 +299,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #endif
         const bool stage_now = !staged;
         if (!staged) {
-            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBT, TA);
+            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTs, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
             staged = true;
         }
@@ -510,6 +531,27 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     const float a = u[s * A + i] + es[i];
                     float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
                     if constexpr (CG) pn += P.cg[i];
+                    if constexpr (RAGGED) {
+                        // steps past the horizon in a trajectory's last group: the state stays,
+                        // no stage cost (s is unrolled, pk_nlast wave-uniform: a scalar branch)
+                        if (s > 0 && s >= pk_nlast) {
+                            const bool dead = gi == last_gi;
+                            const float vn = fmaf(P.k3[i], a, dvs[i]);
+                            dps[i] = dead ? dps[i] : pn;
+                            dvs[i] = dead ? dvs[i] : vn;
+                            const float pc = dead ? 0.0f : pn, vc = dead ? 0.0f : vn;
+#if MPPI_PK_RACC3
+                            raccu[i] = fmaf(uc[s * A + i], es[i], raccu[i]);     // (es = 0 there)
+                            racc[i] = fmaf(pc, pc, racc[i]);
+                            raccv[i] = fmaf(vc, vc, raccv[i]);
+#else
+                            racc[i] = fmaf(uc[s * A + i], es[i], racc[i]);
+                            racc[i] = fmaf(pc, pc, racc[i]);
+                            racc[i] = fmaf(vc, vc, racc[i]);
+#endif
+                            continue;
+                        }
+                    }
                     dvs[i] = fmaf(P.k3[i], a, dvs[i]);
                     dps[i] = pn;
 #if MPPI_PK_RACC3
@@ -693,7 +735,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         }
         // thread m adds Philox block m of the horizon over the 4 waves x TPW trajectories, in that
         // order, five trajectories of all four waves (20 loads) in flight at a time
-        float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * TA);
+        float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * Nrow);
         for (int m = threadIdx.x; m < NBT; m += kRolloutThreads) {
             const int r = m / BPG, b = m - r * BPG;          // group and block of the trajectory
             float4 acc[4];
@@ -750,15 +792,15 @@ constexpr int packed_min_waves()
 #endif
 }
 
-template <int A, int NG, bool SAMPLE>
+template <int A, int NG, bool SAMPLE, bool RAGGED>
 __global__ void __launch_bounds__(kRolloutThreads, (packed_min_waves<A, NG>()))
 k_rollout_packed(const RolloutHot h)
 {
-    packed_body<A, NG, SAMPLE, false>(h, DeferredCombine());
+    packed_body<A, NG, SAMPLE, false, RAGGED>(h, DeferredCombine());
 }
 
 // the same with the previous solve's combine riding at the front of the grid (see k_rollout_ride)
-template <int A, int NG, bool SAMPLE>
+template <int A, int NG, bool SAMPLE, bool RAGGED>
 __global__ void __launch_bounds__(kRolloutThreads, (packed_min_waves<A, NG>()))
 k_rollout_packed_ride(const RolloutHot h, const DeferredCombine d)
 {
@@ -772,51 +814,57 @@ k_rollout_packed_ride(const RolloutHot h, const DeferredCombine d)
         MPPI_STAMP(10);
         return;
     }
-    packed_body<A, NG, SAMPLE, true>(h, d);
+    packed_body<A, NG, SAMPLE, true, RAGGED>(h, d);
 }
 
 template <int A, int NG>
-size_t packed_lds_bytes_t(int NBT, int TPW)
+size_t packed_lds_bytes_t(int NBT /* blocks of the controls staged: NGT*BPG */, int TPW)
 {
     return (size_t)NBT * 2 * 16 + (size_t)4 * kPkRow * NG * Dim<A>::BPG * 16
            + (size_t)(8 + 4 * (TPW + 2)) * sizeof(float);
+}
+
+// the instantiation a launch geometry runs: sampled / injected noise, with / without a riding
+// combine, whole-groups / ragged horizon
+template <int A, int NG>
+const void* packed_kernel(bool sample, bool ride, bool ragged)
+{
+    switch ((sample ? 1 : 0) | (ride ? 2 : 0) | (ragged ? 4 : 0)) {
+        case 0: return reinterpret_cast<const void*>(&k_rollout_packed<A, NG, false, false>);
+        case 1: return reinterpret_cast<const void*>(&k_rollout_packed<A, NG, true, false>);
+        case 2: return reinterpret_cast<const void*>(&k_rollout_packed_ride<A, NG, false, false>);
+        case 3: return reinterpret_cast<const void*>(&k_rollout_packed_ride<A, NG, true, false>);
+        case 4: return reinterpret_cast<const void*>(&k_rollout_packed<A, NG, false, true>);
+        case 5: return reinterpret_cast<const void*>(&k_rollout_packed<A, NG, true, true>);
+        case 6: return reinterpret_cast<const void*>(&k_rollout_packed_ride<A, NG, false, true>);
+        default: return reinterpret_cast<const void*>(&k_rollout_packed_ride<A, NG, true, true>);
+    }
 }
 
 template <int A, int NG>
 hipError_t launch_packed_t(bool sample, int grid, const RolloutArgs& a, const DeferredCombine& d,
                            hipStream_t st, LaunchTiming tm)
 {
-    size_t lds = packed_lds_bytes_t<A, NG>(a.NBT, a.TPW);
-    if (d.n_blocks > 0 && lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
-    const RolloutHot h = make_hot(a);
+    size_t lds = packed_lds_bytes_t<A, NG>(a.NBTp, a.TPW);
+    const bool ride = d.n_blocks > 0;
+    if (ride && lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
+    RolloutHot h = make_hot(a);
+    DeferredCombine dd = d;
     const dim3 g(grid + d.n_blocks), b(kRolloutThreads);
-    if (d.n_blocks > 0) {
-        if (sample) MPPI_LAUNCH((k_rollout_packed_ride<A, NG, true>), g, b, lds, st, tm, h, d);
-        else MPPI_LAUNCH((k_rollout_packed_ride<A, NG, false>), g, b, lds, st, tm, h, d);
-    } else {
-        if (sample) MPPI_LAUNCH((k_rollout_packed<A, NG, true>), g, b, lds, st, tm, h);
-        else MPPI_LAUNCH((k_rollout_packed<A, NG, false>), g, b, lds, st, tm, h);
-    }
-    return hipGetLastError();
+    const void* fn = packed_kernel<A, NG>(sample, ride, a.pk_nlast < Dim<A>::SG);
+    void* args[2] = {&h, &dd};          // (the plain kernel takes the first only)
+    if (tm.start && tm.stop)
+        return hipExtLaunchKernel(fn, g, b, args, lds, st, tm.start, tm.stop, 0);
+    return hipLaunchKernel(fn, g, b, args, lds, st);
 }
 
 template <int A, int NG>      // ride: the riding variant (see fused_blocks_per_cu_t)
-int packed_blocks_per_cu_t(bool sample, size_t lds, bool ride)
+int packed_blocks_per_cu_t(bool sample, size_t lds, bool ride, bool ragged)
 {
     int n = 0;
-    hipError_t rc;
-    if (ride) {
-        if (lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
-        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed_ride<A, NG, true>,
-                                                                   kRolloutThreads, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed_ride<A, NG, false>,
-                                                                   kRolloutThreads, lds);
-    } else {
-        rc = sample ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, true>,
-                                                                   kRolloutThreads, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_rollout_packed<A, NG, false>,
-                                                                   kRolloutThreads, lds);
-    }
+    if (ride && lds < combine_small_lds_bytes()) lds = combine_small_lds_bytes();
+    const hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &n, packed_kernel<A, NG>(sample, ride, ragged), kRolloutThreads, lds);
     return rc == hipSuccess ? n : 0;
 }
 
@@ -845,17 +893,17 @@ hipError_t launch_packed_a(int NG, bool sample, int grid, const RolloutArgs& a,
 }
 
 template <int A>
-int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride)
+int packed_blocks_per_cu_a(int NG, bool sample, size_t lds, bool ride, bool ragged)
 {
     if constexpr (A == 1) {
-        if (NG == 4) return packed_blocks_per_cu_t<1, 4>(sample, lds, ride);
+        if (NG == 4) return packed_blocks_per_cu_t<1, 4>(sample, lds, ride, ragged);
     } else if constexpr (A == 2) {
-        if (NG == 5) return packed_blocks_per_cu_t<2, 5>(sample, lds, ride);
-        if (NG == 8) return packed_blocks_per_cu_t<2, 8>(sample, lds, ride);
+        if (NG == 5) return packed_blocks_per_cu_t<2, 5>(sample, lds, ride, ragged);
+        if (NG == 8) return packed_blocks_per_cu_t<2, 8>(sample, lds, ride, ragged);
     } else if constexpr (A == 3) {
-        if (NG == 4) return packed_blocks_per_cu_t<3, 4>(sample, lds, ride);
+        if (NG == 4) return packed_blocks_per_cu_t<3, 4>(sample, lds, ride, ragged);
     } else {
-        if (NG == 10) return packed_blocks_per_cu_t<4, 10>(sample, lds, ride);
+        if (NG == 10) return packed_blocks_per_cu_t<4, 10>(sample, lds, ride, ragged);
     }
     return 0;
 }

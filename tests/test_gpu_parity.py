@@ -223,6 +223,15 @@ PACKED_CASES = [
     (3, 7, 512, 4, 0),         # 128 groups per trajectory: two per wavefront
     (1, 9, 1024, 4, 0),        # 256 groups per trajectory = 64 lanes x 4: exactly one wavefront each
     (2, 21, 10, 5, 0),         # 5 groups per trajectory = one lane each, 64 trajectories per wavefront
+    # ragged horizons: the last group of a trajectory holds fewer steps than a group (masked)
+    (3, 3000, 50, 4, 0),       # the reference's shipped config/point_mass3d.yaml: 12 groups + 2 steps
+    (1, 513, 203, 4, 0),       # 50 groups + 3 steps
+    (3, 300, 51, 4, 0),        # 12 groups + 3 steps
+    (1, 3000, 50, 4, 0),       # the shipped config/point_mass1d.yaml: 12 groups + 2 steps
+    (2, 3000, 51, 8, 0),       # 25 groups + 1 step (act_dim 2: groups of 2 steps)
+    (2, 700, 11, 5, 2),        # 5 groups + 1 step: one lane and a bit per trajectory
+    (3, 2000, 201, 4, 3),      # 50 groups + 1 step on a persistent grid
+    (3, 900, 199, 4, 0),       # 49 groups + 3 steps
 ]
 
 
@@ -282,6 +291,75 @@ def test_packed_kernel_random_shapes_against_oracle(gpu):
     assert done == 30
 
 
+def test_packed_kernel_random_ragged_shapes_against_oracle(gpu):
+    """The sweep above with horizons that are NOT whole groups: T = (groups - 1) * steps per group
+    + 1 .. steps per group - 1 more steps (act_dim 1, 2, 3; act_dim 4 has one step per group)."""
+    rng = np.random.default_rng(20261006)
+    NGS = {1: [4], 2: [5, 8], 3: [4]}
+    SGS = {1: 4, 2: 2, 3: 4}
+    for trial in range(24):
+        A = int(rng.integers(1, 4))
+        ngl = int(rng.choice(NGS[A]))
+        ngt = int(rng.integers(ngl, min(64 * ngl, 140, 1000 // (SGS[A] * A)) + 1))
+        T = (ngt - 1) * SGS[A] + int(rng.integers(1, SGS[A]))
+        K = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1025, 2500]))
+        lam = float(rng.choice([0.5, 1.0, 2.0, 50.0]))
+        c = ol.make_case(A, K, T, seed=3500 + trial, u_scale=float(rng.choice([0.0, 0.05, 0.5])))
+        c["goal"] = rng.standard_normal(2 * A).astype(np.float32)
+        c["w"] = (np.abs(rng.standard_normal(2 * A) * 5) * (rng.random(2 * A) > 0.2)).astype(np.float32)
+        ref = ol.solve(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=lam)
+        with _model(gpu, A, K, T, c, max_blocks=int(rng.choice([0, 1, 3]))) as m:
+            m.set_packing(ngl)
+            m.set_params(lam)
+            m.set_noise(c["E"])
+            act = m.get_act()
+            inf = m.get_inf()
+            geo = m.geometry()
+        assert geo["packed"]
+        assert np.array_equal(inf["e"], c["E"])
+        _check_solve(act, inf, ref, cost_exact=False, lam=lam,
+                     tag=f"packed ragged trial {trial} A{A} K{K} T{T} {geo}")
+        cost, X = ol.rollout(c["x0"], c["U"], c["E"], c["goal"], c["w"], c["dt"], lam=lam, want_X=True)
+        assert np.array_equal(inf["x"], X)
+
+
+@pytest.mark.parametrize("A,K,T,ngl", [(3, 3000, 50, 4), (1, 3000, 50, 4), (2, 2000, 51, 8)])
+def test_packed_ragged_horizon_in_sampling_mode(gpu, A, K, T, ngl):
+    """Sampling mode on a ragged horizon: the packed kernel draws the noise of the strict kernel bit
+    for bit (the stream is defined on (seed, solve, sample, t*A + a), not on the layout), zeroes
+    what lies past T, and the oracle re-run on that noise reproduces the solve; riding and flushed
+    combines give equal bits there too."""
+    c = ol.make_case(A, 1, T, seed=19, u_scale=0.05)
+    res = {}
+    for kind in ("strict", "packed"):
+        with _model(gpu, A, K, T, c, strict=(kind == "strict")) as m:
+            if kind == "packed":
+                m.set_packing(ngl)
+            m.set_seed(77)
+            m.set_params(30.0)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            m.get_act()
+            U1 = m.get_u()
+            act = m.get_act()                       # second solve: solve index 1 in the counters
+            res[kind] = (act, m.get_inf(x=False), U1, m.geometry())
+    assert res["packed"][3]["packed"]
+    assert np.array_equal(res["packed"][1]["e"], res["strict"][1]["e"])
+    act, inf, U1, geo = res["packed"]
+    ref = ol.solve(c["x0"], U1, inf["e"], c["goal"], c["w"], c["dt"], lam=30.0)
+    _check_solve(act, inf, ref, cost_exact=False, lam=30.0, tag=f"packed ragged sampled A{A} K{K} T{T} {geo}")
+    chains = []
+    for blocking in (False, True):
+        with _model(gpu, A, K, T, c) as m:
+            m.set_packing(ngl)
+            m.set_seed(78)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            for _ in range(6):
+                m.get_act() if blocking else m.solve_async()
+            chains.append((m.sync_act(), m.get_u(), m.launch_counts()))
+    assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
+    assert chains[0][2]["riding"] == 5, chains[0][2]
+
+
 def test_packed_kernel_general_goal_and_zero_weights(gpu):
     """Velocity goals != 0 (the scaled position drifts by a constant per step), zero weights on
     single axes (scale 2^-60 instead of sqrt(w)), lambda and inv_s != 1."""
@@ -321,14 +399,17 @@ def test_packed_kernel_general_goal_and_zero_weights(gpu):
     _check_solve(act, inf, ref, cost_exact=False, tag="negative w falls back")
 
 
-def test_packing_is_refused_where_it_does_not_apply(gpu):
+def test_packing_applies_to_ragged_horizons_and_is_refused_where_it_cannot(gpu):
     from mppi_gpu_amd import MppiError
-    c = ol.make_case(3, 100, 50, seed=3)                 # T = 50 is not a multiple of 4 steps
+    # T = 50 at act_dim 3 (the reference's shipped config/point_mass3d.yaml) is 12 groups of 4 steps
+    # and one of 2: packed since round 3 (the steps past T are masked), 19 trajectories per wave
+    c = ol.make_case(3, 100, 50, seed=3)
     with _model(gpu, 3, 100, 50, c) as m:
-        assert not m.geometry()["packed"]
-        with pytest.raises(MppiError):
-            m.set_packing(4)
+        m.set_packing(4)
+        geo = m.geometry()
+        assert geo["packed"] and geo["trajectories_per_wave"] == 19, geo
         m.set_packing(-1)
+        assert not m.geometry()["packed"]
     c = ol.make_case(3, 100, 200, seed=3)
     with _model(gpu, 3, 100, 200, c) as m:
         assert not m.geometry()["packed"]                # a short launch: latency, not throughput
@@ -339,13 +420,20 @@ def test_packing_is_refused_where_it_does_not_apply(gpu):
         assert m.geometry()["packed"]                    # (the refused call changed nothing)
         m.set_packing(-1)
         assert not m.geometry()["packed"]
+    c = ol.make_case(3, 1, 10, seed=3)
+    with _model(gpu, 3, 100, 10, c) as m:                # 3 groups per trajectory < 4 groups per lane
+        with pytest.raises(MppiError):
+            m.set_packing(4)
     c = ol.make_case(3, 1, 200, seed=3)
     with _model(gpu, 3, 12000, 200, c) as m:             # many tiles per block: packed by itself
         assert m.geometry()["packed"] and m.geometry()["trajectories_per_wave"] == 5
+    c = ol.make_case(3, 1, 50, seed=3)
+    with _model(gpu, 3, 60000, 50, c) as m:              # ... and so is a ragged horizon
+        assert m.geometry()["packed"] and m.geometry()["trajectories_per_wave"] == 19
 
 
 @pytest.mark.parametrize("A,K,T,packing", [(3, 12000, 200, 0), (3, 1500, 200, -1), (2, 3000, 200, 8),
-                                            (2, 10000, 200, 0), (1, 700, 33, 0)])
+                                            (2, 10000, 200, 0), (1, 700, 33, 0), (3, 3000, 50, 4)])
 def test_noise_not_materialised_is_regenerated_bit_for_bit(gpu, A, K, T, packing):
     """mppi_set_noise_store(0): the rollout stores no noise (94 % fewer HBM bytes); the solve is
     the same bits, and the noise get_inf hands out -- regenerated from the Philox counters -- equals
