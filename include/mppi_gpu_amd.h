@@ -139,7 +139,8 @@ int mppi_get_layout(mppi_engine* e, int out[4]);
 /* How consecutive solves are enqueued:
  *   0  deferred combine (default).  mppi_solve_async launches the rollout only; the combine
  *      (beta, nabla, update, shift, action) is launched by whatever comes next: if that is another
- *      mppi_solve_async on the same stream and the launch is short (at most two tiles per block),
+ *      mppi_solve_async on the same stream and the launch is short (at most two tiles per block;
+ *      the packed kernel, whose first tile is a code path of its own: a launch of any length),
  *      it RIDES in that launch -- the first blocks of the grid play the combine role while the
  *      rollout blocks draw their Philox / Box-Muller noise (half of the kernel, and independent of
  *      the controls), and each rollout block polls tagged words for the finished controls before
@@ -150,6 +151,12 @@ int mppi_get_layout(mppi_engine* e, int out[4]);
  *   1  eager: every solve launches its rollout and a 1024-thread combine at once (another
  *      summation order: results agree with mode 0 to rounding, not bit for bit). */
 int mppi_set_pipeline(mppi_engine* e, int mode);
+/* The mode in use, and whether the engine chose it itself: after a device watchdog trip (a block
+ * waited in vain for the combine riding in its own launch, or for a peer's exchange words -- a GPU
+ * shared with other work, a rank that never arrived) the engine reports MPPI_ESTATE until
+ * mppi_set_data and from then on runs in mode 1, where no block waits for a block of its own
+ * launch; *degraded = 1 says so.  mppi_set_pipeline(0) asks for riding combines again. */
+int mppi_get_pipeline(mppi_engine* e, int* mode, int* degraded);
 
 /* ---- asynchronous and sharded use (bench, multi-GPU, closed loop) --------------------- */
 

@@ -186,6 +186,12 @@ class PointMassModel:
         """0 deferred combine (default), 1 eager; see the header."""
         check(self._lib.mppi_set_pipeline(self._h, int(mode)))
 
+    def pipeline(self):
+        """{"mode": 0 | 1, "degraded": the engine chose mode 1 itself after a watchdog trip}"""
+        mode, deg = C.c_int(), C.c_int()
+        check(self._lib.mppi_get_pipeline(self._h, C.byref(mode), C.byref(deg)))
+        return {"mode": mode.value, "degraded": bool(deg.value)}
+
     def geometry(self):
         g = (C.c_int * 5)()
         check(self._lib.mppi_get_geometry(self._h, g))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mppi_set_action_limit": (C.c_int, [engine_p, c_float_p]),
     "mppi_set_tuning": (C.c_int, [engine_p, C.c_int, C.c_int, C.c_int]),
     "mppi_set_pipeline": (C.c_int, [engine_p, C.c_int]),
+    "mppi_get_pipeline": (C.c_int, [engine_p, c_int_p, c_int_p]),
     "mppi_set_packing": (C.c_int, [engine_p, C.c_int]),
     "mppi_get_layout": (C.c_int, [engine_p, c_int_p]),
     "mppi_solve_async": (C.c_int, [engine_p, C.c_void_p]),

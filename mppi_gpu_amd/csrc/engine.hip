@@ -93,6 +93,7 @@ struct mppi_engine {
     // tuning aids, read from the environment ONCE at mppi_create (never per launch)
     int tune_combine_splits = 0;            // MPPI_COMBINE_SPLITS: row splits of the combine, 0 = auto
     int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
+    int tune_ride_long = 1;                 // MPPI_RIDE_LONG: packed launches of any length carry it
     long long resident_ride = 0;            // blocks of the riding kernel variant the chip holds at once
     long long n_rollout_launches = 0;       // since creation: rollout launches, those that carried a
     long long n_riding_launches = 0;        // combine, and combines launched on their own
@@ -164,6 +165,7 @@ struct mppi_engine {
     // not been launched yet; it rides at the front of the next solve's rollout launch, or is
     // flushed by whatever needs its results
     int defer = 1;                          // 0 = every solve launches its own combine
+    bool degraded = false;                  // ... because a device watchdog tripped (check_watchdog)
     bool pending = false;
     int pending_mode = 1;                   // 1 = final combine, 2 = peer exchange + final
     unsigned long long pending_xseq = 0;    // exchange sequence number of a pending mode-2 combine
@@ -580,14 +582,28 @@ void read_action(const mppi_engine_t* e, float* next_act)
 // mppi_set_data starts over (it re-uploads the controls and clears the word).
 int check_watchdog(mppi_engine_t* e)
 {
-    if (!e->fault && e->h_err && *e->h_err) e->fault = *e->h_err;
+    if (!e->fault && e->h_err && *e->h_err) {
+        e->fault = *e->h_err;
+        // Degrade instead of stalling again: a block of a launch waited in vain for another block
+        // (a GPU shared with other work, a peer that never arrived).  From here on -- also after
+        // mppi_set_data has cleared the fault -- every solve launches its rollout and its combine
+        // on their own (pipeline mode 1: no block waits for a block of its own launch) until the
+        // caller asks for mode 0 again with mppi_set_pipeline.
+        if (e->defer) {
+            e->defer = 0;
+            e->degraded = true;
+        }
+    }
     if (!e->fault) return MPPI_OK;
     const int code = e->fault;
+    const char* note = e->degraded ? "; the engine has switched to pipeline mode 1 (stand-alone "
+                                     "launches) by itself" : "";
     if (code == 1)
         return fail(MPPI_ESTATE, "peer exchange timed out after %.1f s: a rank did not reach "
-                    "solve %llu", e->xg_timeout_s, e->solve_idx);
+                    "solve %llu (call mppi_set_data to start over)%s", e->xg_timeout_s,
+                    e->solve_idx, note);
     return fail(MPPI_ESTATE, "device watchdog %d: a block gave up waiting for the combine that "
-                "rides in its own launch (call mppi_set_data to start over)", code);
+                "rides in its own launch (call mppi_set_data to start over)%s", code, note);
 }
 
 // forget a reported fault: everything enqueued has drained (the caller settled), so no kernel can
@@ -637,7 +653,16 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
             probe.row_splits = e->tune_combine_splits;
             co_resident = (long long)e->grid + mppi::combine_small_prepare(probe) <= e->resident_ride;
         }
-        if (!carry || e->strict || e->pending_stream != st || !short_launch || !co_resident) {
+        // The PACKED kernel runs its first tile as a copy of its own (rollout_packed_impl.hpp): what
+        // riding adds -- polling for the controls -- is outside its steady-state loop, so a combine
+        // rides in a packed launch of ANY length (C3: 71 -> 68 us per solve).  A launch of more
+        // blocks than the chip holds leans on index-order dispatch alone (the
+        // combine-role blocks come first and hold their slots before a rollout block can wait for
+        // them); the watchdog bounds the wait if that ever fails, and the engine then falls back to
+        // stand-alone launches by itself (check_watchdog).
+        const bool ride_ok = e->packed ? (e->tune_ride_long != 0 || (short_launch && co_resident))
+                                       : (short_launch && co_resident);
+        if (!carry || e->strict || e->pending_stream != st || !ride_ok) {
             const hipStream_t was = e->pending_stream;
             if ((rc = flush_pending(e))) return rc;
             // a solve that moves to another stream must still see the controls of the last one
@@ -780,6 +805,7 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     mppi_engine* e = new mppi_engine();
     if (const char* env = getenv("MPPI_COMBINE_SPLITS")) e->tune_combine_splits = atoi(env);
     if (const char* env = getenv("MPPI_RIDE_MAX_TILES")) e->tune_ride_max_tiles = atoi(env);
+    if (const char* env = getenv("MPPI_RIDE_LONG")) e->tune_ride_long = atoi(env);
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
     e->SG = mppi::rollout_group_steps(A);
     e->BPG = mppi::rollout_group_blocks(A);
@@ -1256,6 +1282,15 @@ int mppi_set_pipeline(mppi_engine* e, int on)
     }
     if (on < 0 || on > 1) return fail(MPPI_EINVAL, "pipeline mode must be 0 or 1");
     e->defer = on == 0 ? 1 : 0;
+    e->degraded = false;        // an explicit choice overrides the watchdog's
+    return MPPI_OK;
+}
+
+int mppi_get_pipeline(mppi_engine* e, int* mode, int* degraded)
+{
+    if (!e || !mode) return fail(MPPI_EINVAL, "null argument");
+    *mode = e->defer ? 0 : 1;
+    if (degraded) *degraded = e->degraded ? 1 : 0;
     return MPPI_OK;
 }
 

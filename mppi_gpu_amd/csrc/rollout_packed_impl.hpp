@@ -150,6 +150,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     // ragged horizon: group `split - 1` of a lane in which trajectory j0 ends is that trajectory's
     // LAST group; its normals with in-group index >= pk_nlast * A lie past the horizon
     const int last_gi = ends_head ? split - 1 : -1;
+    int dead_from[NG];                              // first step of group gi past the horizon
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) dead_from[gq] = (RAGGED && gq == last_gi) ? pk_nlast : SG;
     const int flag0 = (tail_slot || starts0) ? 1 : 0;      // a trajectory starts in my range
     const int n_out = tail_slot ? L - split * SG : L;      // steps of the range handed on
     const float nh = (float)(split * SG), nt = (float)(L - split * SG);
@@ -206,8 +209,6 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #endif
 
     float Mw = INFINITY, Sw = 0.0f;          // this WAVE's running minimum and exp-sum
-    bool first = true;                       // no tile with a valid trajectory folded yet
-    bool staged = false;                     // controls are in LDS (block-uniform)
     // this lane's slot q of the weighted noise sums is bw[q * kPkRow]: layout [wave][q][lane], so
     // that every wave-instruction of the tile loop reads / writes one contiguous 1 KiB row; rows are
     // 65 float4 apart so that the final merge, which gathers one lane of MANY rows per instruction,
@@ -220,7 +221,14 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #else
 #define MPPI_PK_STAMP(i) do { } while (0)
 #endif
-    for (int tb = bid; tb < n_tileblk; tb += nblk) {
+    // The block's FIRST tile is a copy of the tile body of its own (FIRST = true): it alone stages
+    // the controls (in a riding launch: polls for them), runs the once-per-block nominal pass and
+    // writes -- instead of accumulating -- the wave's LDS slots.  Left as run-time flags inside ONE
+    // loop body, the polling code of the riding variant costs the steady-state loop registers and
+    // scalar spills (255 VGPRs / 81 spilled SGPRs against 250 / 43: 4 % per tile); peeled, every
+    // later tile runs the very loop of the plain kernel.
+    auto tile_body = [&](const int tb, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const long long tile = (long long)tb * 4 + wave;           // one wavefront = one tile
         MPPI_PK_STAMP(11);
         const long long kh = tile * TPW + j0, kt = kh + 1;         // local sample indices
@@ -265,7 +273,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     for (int i = 0; i < 4; ++i) e[q * 4 + i] = P.sigma[(q * 4 + i) % A] * z[i];
                 }
                 if constexpr (RAGGED) {     // zero the normals past the horizon
-                    const int thr = (gi == last_gi) ? pk_nlast * A : SG * A;
+                    const int thr = dead_from[gi] * A;
 #pragma unroll
                     for (int idx = A; idx < SG * A; ++idx)
                         e[gi * BPG * 4 + idx] = (idx >= thr) ? 0.0f : e[gi * BPG * 4 + idx];
@@ -297,11 +305,9 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #if MPPI_PK_PRIO
         __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
 #endif
-        const bool stage_now = !staged;
-        if (!staged) {
+        if constexpr (FIRST) {
             if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTs, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
-            staged = true;
         }
         MPPI_PK_STAMP(2);
 
@@ -468,7 +474,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         };
         float dps[A], dvs[A];
 #if MPPI_PK_NOMINAL
-        if (stage_now)      // (block-uniform) the nominal trajectory's state at the lane's first step
+        if constexpr (FIRST)    // the nominal trajectory's state at the lane's first step
             lane_start(std::integral_constant<int, 1>(), dps1, dvs0, dps_nom, dvs_nom);
         lane_start(std::integral_constant<int, 2>(), dps_nom, dvs_nom, dps, dvs);
 #else
@@ -531,17 +537,20 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     const float a = u[s * A + i] + es[i];
                     float pn = fmaf(P.k2[i], a, fmaf(P.k1[i], dvs[i], dps[i]));
                     if constexpr (CG) pn += P.cg[i];
-                    if constexpr (RAGGED) {
-                        // steps past the horizon in a trajectory's last group: the state stays,
-                        // no stage cost (s is unrolled, pk_nlast wave-uniform: a scalar branch)
-                        if (s > 0 && s >= pk_nlast) {
-                            const bool dead = gi == last_gi;
+                    if constexpr (RAGGED && SG > 1) {
+                        // a step past the horizon in a trajectory's last group leaves the state
+                        // where it is and adds no stage cost (its noise is zero already): plain
+                        // selects on a per-lane mask -- as scalar branches on s >= pk_nlast the
+                        // pass grew 1 500 register moves at its block boundaries
+                        if (s > 0) {
+                            const bool dead = dead_from[gi] <= s;
                             const float vn = fmaf(P.k3[i], a, dvs[i]);
-                            dps[i] = dead ? dps[i] : pn;
+                            pn = dead ? dps[i] : pn;
                             dvs[i] = dead ? dvs[i] : vn;
+                            dps[i] = pn;
                             const float pc = dead ? 0.0f : pn, vc = dead ? 0.0f : vn;
 #if MPPI_PK_RACC3
-                            raccu[i] = fmaf(uc[s * A + i], es[i], raccu[i]);     // (es = 0 there)
+                            raccu[i] = fmaf(uc[s * A + i], es[i], raccu[i]);
                             racc[i] = fmaf(pc, pc, racc[i]);
                             raccv[i] = fmaf(vc, vc, raccv[i]);
 #else
@@ -658,11 +667,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         const float m_w = wave_min((ends_head && valid_h) ? ctA : INFINITY);
         if (m_w < INFINITY) {                            // (wave-uniform) a tile past K adds nothing
             const float Mn = fminf(Mw, m_w);
-            const float alpha = first ? 0.0f : expf(-inv_lambda * (Mw - Mn));   // 1 if Mn == Mw
+            const float alpha = FIRST ? 0.0f : expf(-inv_lambda * (Mw - Mn));   // 1 if Mn == Mw
             const float wA = valid_h ? expf(-inv_lambda * (ctA - Mn)) : 0.0f;
             const float wB = valid_t ? expf(-inv_lambda * (ctB - Mn)) : 0.0f;
             const float sw = wave_sum(ends_head ? wA : 0.0f);
-            Sw = first ? sw : fmaf(alpha, Sw, sw);
+            Sw = FIRST ? sw : fmaf(alpha, Sw, sw);
             Mw = Mn;
             MPPI_PK_STAMP(5);
             const unsigned long long kgh = (unsigned long long)(k_offset + kh);
@@ -670,7 +679,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 ((long long)kgh < k_cover && ((unsigned int)kgh & cover_and) == 0u) ? wA : 0.0f;
             const float wBn =
                 ((long long)(kgh + 1) < k_cover && ((unsigned int)(kgh + 1) & cover_and) == 0u) ? wB : 0.0f;
-            if (first) {                                 // first tile of the wave: plain write
+            if constexpr (FIRST) {                       // first tile of the wave: plain write
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     const float wg = (gi < split) ? wAn : wBn;
@@ -682,6 +691,11 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     }
                 }
             } else if (alpha == 1.0f) {                  // running minimum unchanged: accumulate
+                // ... unless every weight of the wave's tile is EXACTLY zero (expf underflows 88
+                // lambda above the running minimum: at the reference's lambda = 1 and path costs of
+                // hundreds that is most tiles): fmaf(0, e, o) = o, so leaving the slots alone is the
+                // same bits.  With spread-out weights nothing is skipped (bench.py reports both).
+                if (__ballot(wAn != 0.0f || wBn != 0.0f) != 0ull) {
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     const float wg = (gi < split) ? wAn : wBn;
@@ -692,6 +706,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                         bw[q * kPkRow] = make_float4(fmaf(wg, e[q * 4], o.x), fmaf(wg, e[q * 4 + 1], o.y),
                                                  fmaf(wg, e[q * 4 + 2], o.z), fmaf(wg, e[q * 4 + 3], o.w));
                     }
+                }
                 }
             } else {                                     // a new minimum: rescale what is there
 #pragma unroll
@@ -707,11 +722,18 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 }
             }
             MPPI_PK_STAMP(6); MPPI_PK_STAMP(7); MPPI_PK_STAMP(8);
-            first = false;
         }
 #ifdef MPPI_TRACE
         ++tile_no;
 #endif
+    };
+    {
+        int tb = bid;
+        if (tb < n_tileblk) {        // (always: the grid never has more blocks than tile groups)
+            tile_body(tb, std::true_type());
+            tb += nblk;
+        }
+        for (; tb < n_tileblk; tb += nblk) tile_body(tb, std::false_type());
     }
 #undef MPPI_PK_STAMP
     MPPI_STAMP(9);

@@ -935,9 +935,25 @@ def test_device_time_out_is_sticky_until_set_data(gpu):
             with pytest.raises(MppiError) as ei:
                 call()
             assert ei.value.code == -4                      # MPPI_ESTATE, every time
+        assert "switched to pipeline mode 1" in str(ei.value)
+        assert m.pipeline() == {"mode": 1, "degraded": True}
         m.memcpy_set_data(c["x0"], U_before, c["goal"], c["w"])      # starts over
         assert np.array_equal(m.get_u(), U_before)
         assert np.all(np.isfinite(m.get_act()))
+        # ... and stays degraded: solves enqueued back to back no longer ride (no block of a launch
+        # waits for another block of it) until the caller asks for mode 0 again
+        before = m.launch_counts()
+        for _ in range(4):
+            m.solve_async()
+        m.sync_act()
+        after = m.launch_counts()
+        assert after["riding"] == before["riding"] and after["rollout"] == before["rollout"] + 4
+        m.set_pipeline(0)
+        assert m.pipeline() == {"mode": 0, "degraded": False}
+        for _ in range(4):
+            m.solve_async()
+        m.sync_act()
+        assert m.launch_counts()["riding"] == after["riding"] + 3
 
 
 def test_sharded_engines_equal_single_engine(gpu):
