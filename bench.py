@@ -150,6 +150,52 @@ def measured_hbm_peak(torch, n_bytes=1 << 30, reps=12):
             "what": "torch device copy / zero-fill of 1 GiB, best of %d, bytes read + written" % reps}
 
 
+def ess_of(weights):
+    """Effective sample size 1 / sum(w^2) of normalised weights (float64)."""
+    import numpy as np
+    w = np.asarray(weights, np.float64)
+    tot = w.sum()
+    if not tot > 0:
+        return 0.0
+    w = w / tot
+    return float(1.0 / np.sum(w * w))
+
+
+def lambda_for_ess(cost, target):
+    """lambda at which the softmax of -cost / lambda has the effective sample size `target`
+    (bisection in log lambda on the path costs the engine reported; chooses a workload, checks
+    nothing: the ESS a run ACHIEVED is read from its own weights afterwards)."""
+    import numpy as np
+    c = np.asarray(cost, np.float64)
+    c = c - c.min()
+
+    def ess(lam):
+        w = np.exp(-c / lam)
+        return float(w.sum() ** 2 / np.sum(w * w))
+
+    lo, hi = 1e-2, 1e7
+    for _ in range(60):
+        mid = float(np.sqrt(lo * hi))
+        lo, hi = (mid, hi) if ess(mid) < target else (lo, mid)
+    return float(np.sqrt(lo * hi))
+
+
+def spread_weights_leg(m, K, n_warm, n):
+    """The same engine and workload with lambda chosen so that about a third of the batch carries
+    weight (the reference hard-codes lambda = 1, src/point_mass.cu:53-54).  The kernels run the
+    same instructions whatever the weights: the time must not depend on lambda."""
+    cost = m.get_inf(x=False, u=False, e=False, beta=False, nabla=False, weight=False)["cost"]
+    lam = lambda_for_ess(cost, K / 3.0)
+    m.set_params(lam)
+    dt_v, k_v, k_nv, c_v = timed_engine_run(m, n_warm, n)
+    w = m.get_inf(x=False, u=False, e=False, cost=False, beta=False, nabla=False)["weight"]
+    m.set_params(1.0)
+    return {"what": "the same workload with lambda chosen for an effective sample size near K/3; "
+                    "lambda = 1 is the reference's hard-coded value",
+            "lambda": lam, "ess": round(ess_of(w), 1), "ms_per_step": dt_v * 1e3,
+            "value": K / dt_v, "rollout_kernel_ms": round(k_v, 5)}
+
+
 def quantiles(xs):
     xs = sorted(xs)
     n = len(xs)
@@ -163,7 +209,7 @@ def committed_profile(name):
         return None
 
 
-def roofline_entry(workload, K, T, A, geo, riding, k_ms, k_n, c_ms):
+def roofline_entry(workload, K, T, A, geo, riding, k_ms, k_n, c_ms, solve_ms=None):
     """The `roofline` object of one workload from the live event timing of its rollout launches.
     PMC counters cannot be collected from inside the timed process: `traffic`, the rocprofv3
     kernel duration and the VALU figures come from the COMMITTED summaries of this workload and
@@ -195,6 +241,13 @@ def roofline_entry(workload, K, T, A, geo, riding, k_ms, k_n, c_ms):
             "kernel_ms_source": "HIP events stamped on the dispatch (hipExtLaunchKernelGGL), "
                                 "second launch of each stamped pair, inside the timed region",
             "launches_timed": k_n, "combine_kernel_ms": round(c_ms, 5)}
+    if solve_ms:
+        # the same algorithmic bytes over the WHOLE solve (wall time per step of the timed region:
+        # rollout + combine + whatever lies between the launches), what north_star's ">= 40 % of
+        # the HBM roofline" at rollouts/s of the solve is stated on
+        roof["solve_frac"] = round(ab / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["solve_frac_what"] = ("algorithmic_bytes_per_launch / ms_per_step / peak: the solve, "
+                                   "not the kernel")
     aj = committed_profile(PROFILE_ALU)
     if aj and not geo["strict"]:
         ent = aj["entries"].get(prof_key)
@@ -211,9 +264,17 @@ def roofline_entry(workload, K, T, A, geo, riding, k_ms, k_n, c_ms):
     return roof
 
 
-def timed_engine_run(m, n_warm, n, every=8):
+def timed_engine_run(m, n_warm, n, every=32, ramp_ms=30.0):
     """n solves enqueued back to back on engine m: (seconds per solve, rollout kernel ms, launches
-    stamped, combine kernel ms)."""
+    stamped, combine kernel ms).  Every leg first keeps the GPU busy for ramp_ms: whatever came
+    before it (creating an engine, reading costs back, a host-side bisection) left the device idle
+    for milliseconds, and a leg measured on the way back up from the idle clocks reads 10-20 %
+    slow (C3: 79 against 66.7 us per solve, tools/lambda_speed.py)."""
+    t_r = time.perf_counter()
+    while time.perf_counter() - t_r < ramp_ms * 1e-3:
+        for _ in range(20):
+            m.solve_async()
+        m.sync_act()
     for _ in range(n_warm):
         m.solve_async()
     m.sync_act()
@@ -243,7 +304,25 @@ def spawn_ranks(n_gpus):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
+    # poll: a rank that dies would leave the others waiting in a collective until its time-out
+    codes = [None] * n_gpus
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):           # exactly the processes started above
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
     sys.exit(max(abs(c) for c in codes))
 
 
@@ -361,8 +440,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # stamped launches: every n-th solve and its successor.  Stamping costs ~7 us of host and
+    # dispatch time per stamped launch (hipExtLaunchKernelGGL), so the timed region is stamped
+    # sparsely whatever its length; a SHORT run (the driver's --steps 20 holds one stamped pair) is
+    # followed by an untimed profiling batch, see below
+    event_every = max(2, args.event_every)
     if not args.no_events:
-        m.set_profiling(max(1, args.event_every))
+        m.set_profiling(event_every)
     fence()
     cnt0 = m.launch_counts()
     t0 = time.perf_counter()
@@ -387,7 +471,29 @@ def main():
     if not args.no_events:
         k_ms, k_n = m.kernel_ms(0)
         c_ms, _ = m.kernel_ms(1)
-        roof = roofline_entry(args.workload, K, T, A, geo, riding, k_ms, k_n, c_ms)
+        k_n_region = k_n
+        if k_n < 16 and not args.blocking:
+            # too few stamped launches inside the timed region for a mean: the SAME engine goes on
+            # for an untimed batch of 160 solves with every 4th pair stamped (the stamps of the
+            # timed region stay in the mean)
+            m.set_profiling(0)
+            before = (k_ms * k_n, k_n)
+            m.set_profiling(4)
+            for _ in range(160):
+                step()
+            fence()
+            kb_ms, kb_n = m.kernel_ms(0)
+            c_ms, _ = m.kernel_ms(1)
+            k_n = before[1] + kb_n
+            k_ms = (before[0] + kb_ms * kb_n) / max(1, k_n)
+        roof = roofline_entry(args.workload, K, T, A, geo, riding, k_ms, k_n, c_ms,
+                              solve_ms=dt_s / args.steps * 1e3)
+        roof["event_every"] = event_every
+        roof["launches_timed_in_region"] = k_n_region
+        if k_n != k_n_region:
+            roof["kernel_ms_source"] += ("; the timed region held %d stamped launch(es), the other "
+                                         "%d come from an untimed batch of 160 solves run right "
+                                         "after it on the same engine" % (k_n_region, k_n - k_n_region))
         if riding and sharded is None:
             # for reference, outside the timed region: the two kernels on their own (eager mode,
             # one rollout launch + one combine launch per solve)
@@ -460,8 +566,18 @@ def main():
                    "what": "PointMassModel.get_act() through the Python binding: launch, solve, "
                            "wait for the action in host memory (reference src/main.cu:329-332)"}
 
+    # effective sample size of the benchmark's last solve (lambda = 1, the reference's value): says
+    # in which regime the exp-weighted update ran
+    ess_line = None
+    if not args.inject:
+        try:
+            ess_line = round(ess_of(m.get_inf(x=False, u=False, e=False, cost=False, beta=False,
+                                              nabla=False)["weight"]), 1)
+        except Exception:
+            ess_line = None
     extra = {}
     if N == 1 and sharded is None and not (args.blocking or args.inject or args.strict or args.no_events):
+        extra["spread_weights"] = spread_weights_leg(m, K, 100, min(args.steps, 500))
         # ---- the same workload with the noise NOT materialised (mppi_set_noise_store(0)): a
         #      reported variant, never the headline (E is an observable of the reference) --------
         m.set_noise_store(False)
@@ -487,7 +603,12 @@ def main():
             riding3 = c3c["riding"] > c3c["rollout"] // 2
             extra["c3"] = {"workload": desc3, "ms_per_step": dt3 * 1e3, "value": K3 / dt3,
                            "unit": "rollouts/s", "steps": 400, "geometry": geo3,
-                           "roofline": roofline_entry("c3", K3, T3, A3, geo3, riding3, k3, kn3, cm3)}
+                           "roofline": roofline_entry("c3", K3, T3, A3, geo3, riding3, k3, kn3, cm3,
+                                                      solve_ms=dt3 * 1e3),
+                           "launches": c3c}
+            extra["c3"]["ess"] = round(ess_of(m3.get_inf(x=False, u=False, e=False, cost=False,
+                                                         beta=False, nabla=False)["weight"]), 1)
+            extra["c3"]["spread_weights"] = spread_weights_leg(m3, K3, 30, 200)
             m3.set_noise_store(False)
             dt3n, k3n, _, _ = timed_engine_run(m3, 30, 200)
             extra["c3"]["noise_not_materialised"] = {"ms_per_step": dt3n * 1e3,
@@ -532,6 +653,10 @@ def main():
                      "synthetic"),
             "config": {"workload": desc, "rollouts_per_gpu": K, "horizon": T, "act_dim": A,
                        "global_rollouts": N * K, "sharding": f"samples x{N}",
+                       "lambda": 1.0, "ess": ess_line,
+                       "ess_what": "effective sample size 1/sum(w^2) of the last solve (this rank's "
+                                   "shard): ~1 = the softmax is one-hot at the reference's lambda = 1; "
+                                   "extra.spread_weights times the same workload at ESS ~ K/3",
                        "mode": "blocking get_act per step" if args.blocking else
                                "solves enqueued back to back (mppi_solve_async), one wait at the end",
                        "exchange": None if sharded is None else

@@ -258,9 +258,17 @@ int ensure_geometry(mppi_engine_t* e)
         // the row-aligned kernel's shorter tail wins (measured 12.0 against 14.4 us at C2).
         if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
             packed = false;
-        if (packed && e->user_packing <= 0 &&
-            mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) > 64 * 1024)
+        const bool pk_fits = pk_NG > 0 &&
+                             mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) <= 64 * 1024;
+        if (packed && e->user_packing <= 0 && !pk_fits)
             packed = false;          // horizon too long for the LDS slots: row-aligned kernel
+        if (!packed && e->user_packing == 0 && pk_fits) {
+            // ... and the other way round: a horizon whose row-aligned tile does not fit the LDS
+            // (the per-wave weighted-noise rows grow with T*A) may still fit the packed one
+            const int nq_row = ng * e->BPG;
+            const int NBTp_row = (C * nq_row > e->NBT) ? C * nq_row : e->NBT;
+            if (mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4) > 64 * 1024) packed = true;
+        }
     }
     if (packed) {
         C = 1;                      // (unused by the packed kernel)

@@ -691,11 +691,10 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     }
                 }
             } else if (alpha == 1.0f) {                  // running minimum unchanged: accumulate
-                // ... unless every weight of the wave's tile is EXACTLY zero (expf underflows 88
-                // lambda above the running minimum: at the reference's lambda = 1 and path costs of
-                // hundreds that is most tiles): fmaf(0, e, o) = o, so leaving the slots alone is the
-                // same bits.  With spread-out weights nothing is skipped (bench.py reports both).
-                if (__ballot(wAn != 0.0f || wBn != 0.0f) != 0ull) {
+                // (measured and dropped: skipping the accumulate of a tile whose weights are all
+                //  exactly zero -- same bits -- changes nothing even at lambda = 0.05, where all but
+                //  one tile skip: 66.3 against 66.1 us at C3; the LDS traffic of this tail hides
+                //  under the other wave's Philox pass.  tools/lambda_speed.py)
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) {
                     const float wg = (gi < split) ? wAn : wBn;
@@ -706,7 +705,6 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                         bw[q * kPkRow] = make_float4(fmaf(wg, e[q * 4], o.x), fmaf(wg, e[q * 4 + 1], o.y),
                                                  fmaf(wg, e[q * 4 + 2], o.z), fmaf(wg, e[q * 4 + 3], o.w));
                     }
-                }
                 }
             } else {                                     // a new minimum: rescale what is there
 #pragma unroll

@@ -2,7 +2,8 @@
 inputs.  Floating point, so tolerances are stated here:
 
   strict kernel  (one lane per trajectory, sequential)   cost: BIT-EXACT, beta: exact
-  fused kernels  (lanes share a trajectory, scan + tree) cost: rtol 3e-6 (achieved <= 2.0e-6)
+  fused kernels  (lanes share a trajectory, scan + tree) cost: rtol max(3e-6, 0.35 T 2^-24): 4.2e-6 at T = 200
+                                                         (achieved <= 2.0e-6 there), 2.1e-5 at T = 1000
   both                                                   nabla: rtol 2e-6 (strict) / max(1e-4, 8 ulp(c)/lambda) (fused)
                                                          weights: rtol 2e-5 (strict) / max(1e-3, 16 ulp(c)/lambda) (fused)
                                                          U, action: max-norm rel 1e-5
@@ -57,6 +58,11 @@ def _model(gpu, A, K, T, case, chunks=0, strict=False, max_blocks=0):
 
 
 ESS_PLAIN = 32.0         # effective samples from which the fused kernel must meet the plain bar
+
+
+def cost_rtol(T):
+    """Bar on the path costs of the fused kernels against the oracle, as a function of the horizon."""
+    return max(3e-6, 0.35 * T * 2.0 ** -24)
 _RECORDS = []
 
 
@@ -130,10 +136,14 @@ def _check_solve(got_act, inf, ref, cost_exact, tag="", lam=1.0, emax=4.5 * SIGM
         assert np.array_equal(inf["cost"], ref["cost"]), f"{tag}: cost not bit-exact"
         assert np.float32(inf["beta"]) == ref["beta"], tag
     else:
-        # (the worst of a million samples reaches 2.0e-6, profiles/parity_r02.json: 600 rounded
-        #  additions per path cost; the typical sample is at 4e-7)
-        np.testing.assert_allclose(inf["cost"], ref["cost"], rtol=3e-6, atol=0, err_msg=tag)
-        np.testing.assert_allclose(inf["beta"], ref["beta"], rtol=3e-6, err_msg=tag)
+        # (the worst of a million samples reaches 2.0e-6 at T = 200: 600 rounded additions per
+        #  path cost; the typical sample is at 4e-7).  Two fp32 evaluations of a T-step recurrence
+        #  drift apart with T: the bar is COST_RTOL(T) = max(3e-6, 0.35 T 2^-24) -- 3e-6 up to
+        #  T = 143, 4.2e-6 at 200, 1.1e-5 at 512, 2.1e-5 at 1000; tools/sweep_cost_error.py
+        #  (profiles/r03_sweep_cost_error.txt) finds <= 0.23 T 2^-24 in both fused kernels alike.
+        c_rtol = cost_rtol(int(T if T is not None else inf["u"].shape[0]))
+        np.testing.assert_allclose(inf["cost"], ref["cost"], rtol=c_rtol, atol=0, err_msg=tag)
+        np.testing.assert_allclose(inf["beta"], ref["beta"], rtol=c_rtol, err_msg=tag)
     # fused kernel: a weight moves by (cost difference)/lambda RELATIVE, i.e. by a few ulp(cost)/lambda
     ulp_c = float(np.spacing(np.float32(np.abs(ref["cost"]).max()))) / lam
     if spread > 0:
@@ -169,6 +179,9 @@ CASES = [
     (4, 130, 37),
     (1, 513, 203),     # ragged horizon for 4 steps per Philox block
     (2, 64, 1),        # single step
+    (1, 300, 512),     # long horizons: the cost bar grows with T (cost_rtol)
+    (1, 200, 1000),
+    (3, 100, 512),
 ]
 
 
@@ -223,6 +236,10 @@ PACKED_CASES = [
     (3, 7, 512, 4, 0),         # 128 groups per trajectory: two per wavefront
     (1, 9, 1024, 4, 0),        # 256 groups per trajectory = 64 lanes x 4: exactly one wavefront each
     (2, 21, 10, 5, 0),         # 5 groups per trajectory = one lane each, 64 trajectories per wavefront
+    (1, 300, 512, 4, 0),       # long horizons: the cost bar grows with T (cost_rtol)
+    (1, 200, 1000, 4, 0),
+    (3, 100, 512, 4, 0),
+    (2, 100, 1000, 8, 0),
     # ragged horizons: the last group of a trajectory holds fewer steps than a group (masked)
     (3, 3000, 50, 4, 0),       # the reference's shipped config/point_mass3d.yaml: 12 groups + 2 steps
     (1, 513, 203, 4, 0),       # 50 groups + 3 steps
