@@ -48,8 +48,8 @@ WORKLOADS = {
     "c4full": (3, 1_000_000, 200, "point_mass3d K=1e6 T=200 on ONE GPU (BASELINE configs[3] unsharded)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PROFILE_TRAFFIC = "traffic_r02.json"   # committed rocprofv3 --pmc summaries (profiles/README.md)
-PROFILE_ALU = "alu_r02.json"
+PROFILE_TRAFFIC = "traffic_r03.json"   # committed rocprofv3 --pmc summaries (profiles/README.md)
+PROFILE_ALU = "alu_r03.json"
 
 
 def algorithmic_bytes_rollout(K, T, A):
@@ -194,6 +194,179 @@ def spread_weights_leg(m, K, n_warm, n):
                     "lambda = 1 is the reference's hard-coded value",
             "lambda": lam, "ess": round(ess_of(w), 1), "ms_per_step": dt_v * 1e3,
             "value": K / dt_v, "rollout_kernel_ms": round(k_v, 5)}
+
+
+def pmc_child_passes(workload, kernel_sub, counter_sets, extra_args=()):
+    """Run this file as a child under `rocprofv3 --kernel-trace --pmc <set>` once per counter set
+    (counters in their own runs, --kernel-trace only) and return, for the kernel whose name contains
+    `kernel_sub`: ({counter: mean value per dispatch}, mean dispatch duration in us, dispatches)
+    or (None, reason, 0)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found", 0
+    vals, durs = {}, []
+    tmp = tempfile.mkdtemp(prefix="mppi_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for n, cset in enumerate(counter_sets):
+            d = os.path.join(tmp, f"pass{n}")
+            cmd = [exe, "--kernel-trace", "--pmc", *cset, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "20",
+                   "--warmup", "5", "--ramp-ms", "0", "--no-cpu-baseline", "--no-events", "--no-pmc",
+                   "--no-extra", "--no-latency", *extra_args]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {' '.join(cset)} failed: {r.stderr.strip()[-200:]}", 0
+            for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    if kernel_sub in row["Kernel_Name"]:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
+                for row in csv.DictReader(open(f)):
+                    if kernel_sub in row["Kernel_Name"]:
+                        durs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return None, f"child profiling run: {ex}", 0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    want = [c for cset in counter_sets for c in cset]
+    missing = [c for c in want if c not in vals]
+    if missing:
+        return None, f"no rows for {missing} of a kernel named *{kernel_sub}*", 0
+    n = min(len(v) for v in vals.values())
+    return {c: sum(v) / len(v) for c, v in vals.items()}, (sum(durs) / len(durs) if durs else 0.0), n
+
+
+def pmc_traffic_live(workload, kernel_sub, extra_args=()):
+    """HBM bytes per launch, measured NOW (guides/MI355X_MICROARCH.md "HBM"): FETCH_SIZE and
+    WRITE_SIZE are in KiB, one TCC counter per pass; gfx950 counts the bytes of a wide coalesced
+    read at half -> FETCH_SIZE x 2; WRITE_SIZE is exact for 16-byte-per-lane streaming stores."""
+    v, why, n = pmc_child_passes(workload, kernel_sub, [["FETCH_SIZE"], ["WRITE_SIZE"]], extra_args)
+    if v is None:
+        return None, why
+    fetch, write = v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
+    return {"hbm_bytes_per_launch": round(2 * fetch + write), "fetch_bytes_raw": round(fetch),
+            "fetch_bytes_corrected_x2": round(2 * fetch), "write_bytes": round(write),
+            "dispatches": n}, None
+
+
+def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=()):
+    """Mean duration of the kernel by `rocprofv3 --kernel-trace --stats` over a child run of this
+    command (200 solves behind the clock ramp; no counters): what the committed
+    profiles/*_kernel_stats.csv hold, measured NOW.  (ms, calls) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mppi_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--",
+               sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "200",
+               "--warmup", "20", "--no-cpu-baseline", "--no-events", "--no-pmc", "--no-extra",
+               "--no-latency", *extra_args]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True,
+                           text=True, timeout=180)
+        if r.returncode != 0:
+            return None, f"rocprofv3 --stats failed: {r.stderr.strip()[-200:]}"
+        for f in glob.glob(os.path.join(tmp, "*", "*kernel_stats.csv")):
+            for row in csv.DictReader(open(f)):
+                if kernel_sub in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6, int(row["Calls"])
+        return None, f"no kernel named *{kernel_sub}* in the stats"
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return None, f"child profiling run: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# issue cost of a wave64 instruction in SIMD cycles at the nominal 2.4 GHz, measured with
+# tools/ubench_issue on MI355X (profiles/r02_ubench_issue.txt)
+ISSUE_COST = {"INT64": 6.3, "TRANS_F32": 8.4, "BITOP3": 4.2, "OTHER": 2.3}
+
+
+def pmc_alu_live(workload, kernel_sub, extra_args=()):
+    """The VALU side of the roofline, measured NOW: instruction counts by class, the counter-based
+    VALU busy (rocprof's VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE) and the
+    issue-cycle model (count x measured issue cycles per class / SIMD cycles of the launch)."""
+    sets = [["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F32",
+             "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32"],
+            ["SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"], ["GRBM_GUI_ACTIVE"]]
+    v, dur_us, n = pmc_child_passes(workload, kernel_sub, sets, extra_args)
+    if v is None:
+        return None, dur_us
+    n_simd, f_nom = 1024, 2.4e9
+    n_all, n64, ntr = v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU_INT64"], v["SQ_INSTS_VALU_TRANS_F32"]
+    nb3 = n64                       # one v_bitop3_b32 per v_mad_u64_u32 (two of each per Philox round)
+    cyc = (n64 * ISSUE_COST["INT64"] + ntr * ISSUE_COST["TRANS_F32"] + nb3 * ISSUE_COST["BITOP3"]
+           + (n_all - n64 - ntr - nb3) * ISSUE_COST["OTHER"])
+    gui = v["GRBM_GUI_ACTIVE"]
+    inst = 8.0 if dur_us > 0 and gui / (dur_us * 1e-6) > 6e9 else 1.0    # summed over the 8 XCDs, or not
+    gui_cycles = gui / inst
+    return {"bound": "valu", "achieved": round(cyc / (n_simd * dur_us * 1e-6 * f_nom), 4), "peak": 1.0,
+            "unit": "fraction of the launch's VALU issue cycles (issue-cycle model)",
+            "valu_busy_counter": round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / gui_cycles, 4),
+            "valu_instructions_per_launch": round(n_all), "v_mad_u64_u32": round(n64),
+            "transcendental": round(ntr), "fma_f32": round(v["SQ_INSTS_VALU_FMA_F32"]),
+            "add_f32": round(v["SQ_INSTS_VALU_ADD_F32"]), "mul_f32": round(v["SQ_INSTS_VALU_MUL_F32"]),
+            "wait_any_fraction_of_wave_cycles": round(v["SQ_WAIT_ANY"] / max(1.0, v["SQ_WAVE_CYCLES"]), 4),
+            "kernel_us_in_these_passes": round(dur_us, 3), "dispatches": n,
+            "source": "measured in this run: three child passes of this command under rocprofv3 "
+                      "--kernel-trace --pmc (SQ instruction counters; SQ_ACTIVE_INST_VALU; "
+                      "GRBM_GUI_ACTIVE), per-class issue costs from profiles/r02_ubench_issue.txt"}, None
+
+
+def kernel_symbol(geo, riding, A):
+    """Name (up to the first template argument) of the rollout kernel a geometry launches."""
+    if geo["strict"]:
+        return f"k_rollout_stream<{A}"
+    if geo["packed"]:
+        return (f"k_rollout_packed_ride<{A}" if riding else f"k_rollout_packed<{A}")
+    return f"k_rollout_ride<{A}" if riding else f"k_rollout_fused<{A}"
+
+
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def attach_live_traffic(roof, workload, kernel_sub, extra_args=()):
+    """Replace roof['traffic'] (from the committed summaries) with a live PMC measurement."""
+    if roof is None:
+        return
+    t, why = pmc_traffic_live(workload, kernel_sub, extra_args)
+    if t is None:
+        roof["traffic_live_error"] = why
+        return
+    roof["traffic"] = t["hbm_bytes_per_launch"]
+    roof["traffic_detail"] = t
+    roof["traffic_over_algorithmic"] = round(t["hbm_bytes_per_launch"]
+                                             / roof["algorithmic_bytes_per_launch"], 4)
+    roof["traffic_source"] = ("measured in this run: two child passes of this command under rocprofv3 "
+                              "--kernel-trace --pmc (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass), "
+                              "mean over %d dispatches of %s" % (t["dispatches"], kernel_sub))
+    a, why = pmc_alu_live(workload, kernel_sub, extra_args)
+    if a is None:
+        roof["alu_live_error"] = why
+    else:
+        roof["alu"] = a
+    km, calls = rocprof_kernel_ms_live(workload, kernel_sub, extra_args)
+    if km is None:
+        roof["kernel_ms_rocprof_error"] = calls
+    else:
+        roof["kernel_ms_rocprof"] = round(km, 6)
+        roof["frac_rocprof"] = round(roof["algorithmic_bytes_per_launch"] / (km * 1e-3) / 1e9
+                                     / roof["peak"], 4)
+        roof["kernel_ms_rocprof_source"] = ("measured in this run: child pass under rocprofv3 "
+                                            "--kernel-trace --stats, mean of %d dispatches" % calls)
 
 
 def quantiles(xs):
@@ -360,6 +533,11 @@ def main():
                          "with one rank: rehearsal of the N > 1 path on a one-GPU box")
     ap.add_argument("--inject", action="store_true",
                     help="ANALYSIS ONLY: injected-noise mode (no sampling); not a valid bench result")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic live (child rocprofv3 --pmc passes); the "
+                         "committed summary under profiles/ is quoted instead")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no extra.* legs)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the blocking get_act latency leg")
     ap.add_argument("--event-every", type=int, default=32,
                     help="record HIP events around the kernels of every n-th timed solve")
     args = ap.parse_args()
@@ -520,7 +698,7 @@ def main():
 
     # ---- the reference's timed unit: a blocking get_act (+ set_x: the closed loop) -----------
     latency = None
-    if not args.blocking and not args.inject:
+    if not args.blocking and not args.inject and not args.no_latency:
         eng = sharded or m
         n_lat = 300 if K <= 200_000 else 50
         x_now = c["x0"].copy()
@@ -576,7 +754,8 @@ def main():
         except Exception:
             ess_line = None
     extra = {}
-    if N == 1 and sharded is None and not (args.blocking or args.inject or args.strict or args.no_events):
+    if N == 1 and sharded is None and not (args.blocking or args.inject or args.strict
+                                           or args.no_events or args.no_extra):
         extra["spread_weights"] = spread_weights_leg(m, K, 100, min(args.steps, 500))
         # ---- the same workload with the noise NOT materialised (mppi_set_noise_store(0)): a
         #      reported variant, never the headline (E is an observable of the reference) --------
@@ -640,6 +819,23 @@ def main():
                        "value": K4 * n4 / d4, "unit": "rollouts/s", "scaling": "strong",
                        "exchange": s4.transport, "exchange_validated": getattr(s4, "validated", None)}
         s4.close()
+
+    # ---- roofline.traffic, live: the engines of this process are idle from here on --------------
+    if rank == 0 and N == 1 and sharded is None and roof is not None and not args.no_pmc \
+            and not under_profiler() and not args.inject:
+        fwd = []
+        if args.packing:
+            fwd += ["--packing", str(args.packing)]
+        if args.chunks:
+            fwd += ["--chunks", str(args.chunks)]
+        if args.pipeline:
+            fwd += ["--pipeline", str(args.pipeline)]
+        attach_live_traffic(roof, args.workload, kernel_symbol(geo, riding, A), fwd)
+        c3x = extra.get("c3")
+        if c3x:
+            attach_live_traffic(c3x["roofline"], "c3",
+                                kernel_symbol(c3x["geometry"], c3x["launches"]["riding"]
+                                              > c3x["launches"]["rollout"] // 2, 3))
 
     if rank == 0:
         value = N * K * args.steps / dt_s
