@@ -61,6 +61,19 @@ __device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigne
     const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#ifndef MPPI_FIN_SCOPE_AGENT
+#define MPPI_FIN_SCOPE_AGENT 0     // experiment: agent-scope stores for words that stay on this GPU
+#endif
+// a tagged word read only by blocks of THIS device (row-split sums, finished controls)
+__device__ __forceinline__ void ll_store_local(unsigned long long* p, float v, unsigned int tag)
+{
+#if MPPI_FIN_SCOPE_AGENT
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    ll_store(p, v, tag);
+#endif
+}
 
 // Has a block of some launch of this engine already given up waiting?  (the device watchdog
 // word; sticky until mppi_set_data)  Later launches then neither wait nor publish anything.
@@ -150,7 +163,7 @@ __device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int
     if (n < a.TA) {
         const float unew = updated_control(a, n, uin, tot, nabla);
         // (the tagged word first: a rollout block of a riding launch is waiting for it)
-        if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        if (a.slab_tag) ll_store_local(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
         publish_control(a, n, unew);
     }
     if (cb == 0 && tid == 0) {
@@ -165,7 +178,7 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float
     if (a.final_mode) {
         const float unew = updated_control(a, n, uin, tot, nabla);
         // (the tagged word first: a rollout block of a riding launch is waiting for it)
-        if (a.slab_tag) ll_store(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        if (a.slab_tag) ll_store_local(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
         publish_control(a, n, unew);
     } else {
         a.partial_out[2 + n] = tot;
@@ -432,7 +445,7 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a, int bid, cons
         const unsigned int tag = a.tag;
         if (rs != RS - 1) {
             if (tid < kCombineCols && n < a.TA)
-                ll_store(a.slab_tag + (size_t)rs * a.TA + n, tot, tag);
+                ll_store_local(a.slab_tag + (size_t)rs * a.TA + n, tot, tag);
             return;
         }
         if (RS > 1 && tid < kCombineCols && n < a.TA) {

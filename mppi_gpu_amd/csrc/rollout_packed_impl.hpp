@@ -305,11 +305,6 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #if MPPI_PK_PRIO
         __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
 #endif
-        if constexpr (FIRST) {
-            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTs, TA);
-            __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
-        }
-        MPPI_PK_STAMP(2);
 
         // ---- pass 1b + scan: the scaled state every lane starts from.  Zero-state response of the
         //      lane's range(s) to accelerations a: V = dt*S1, P = B0*S1 + dt^2*((n-1)*S1 - S2),
@@ -331,7 +326,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #pragma unroll
             for (int i = 0; i < A; ++i) { S1[i] = 0.f; S2[i] = 0.f; S1h[i] = 0.f; S2h[i] = 0.f; }
             float4 unext[BPG];                      // controls of the NEXT group: loaded a group ahead
-            if constexpr (MODE != 2) {
+            if constexpr (MODE < 2) {
 #pragma unroll
                 for (int b = 0; b < BPG; ++b) unext[b] = ulds[rbh + b];   // (group 0 is always head)
             }
@@ -341,7 +336,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 //  groups to the top of the pass and holds them in registers)
                 MPPI_PK_FENCE();
                 float u[BPG * 4];
-                if constexpr (MODE != 2) {
+                if constexpr (MODE < 2) {
 #if !MPPI_PK_PREFETCH
                     {
                         const int rbc = ((gi < split) ? rbh : rbt) + gi * BPG;
@@ -396,7 +391,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 Pz[i] = fmaf(P.dt2, fmaf(no - 1.0f, S1o, -S2o), P.B0 * S1o);
             }
 #if MPPI_PK_QSCAN
-            if constexpr (MODE == 2) {
+            if constexpr (MODE >= 2) {
                 float Qz[A];
 #pragma unroll
                 for (int i = 0; i < A; ++i) Qz[i] = fmaf(q_ref, Vz[i], Pz[i]);
@@ -427,8 +422,13 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                     float Vex = dpp<kWaveShr1>(Vz[i]);
                     if (starts0) { Qex = 0.f; Vex = 0.f; }
                     const float Pex = fmaf(-c_ref, Vex, Qex);
-                    dps[i] = fmaf(P.sp[i], Pex, bp[i]);
-                    dvs[i] = fmaf(P.sv[i], Vex, bv[i]);
+                    if constexpr (MODE == 3) {      // the raw response: the caller adds the base
+                        dps[i] = Pex;
+                        dvs[i] = Vex;
+                    } else {
+                        dps[i] = fmaf(P.sp[i], Pex, bp[i]);
+                        dvs[i] = fmaf(P.sv[i], Vex, bv[i]);
+                    }
                 }
                 return;
             }
@@ -473,12 +473,39 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             }
         };
         float dps[A], dvs[A];
+#if MPPI_PK_NOMINAL && MPPI_PK_QSCAN
+        // MODE 3 = MODE 2 without the base: the response of the lanes before this one to the NOISE
+        // (Pex, Vex) needs no controls, so on the block's first tile it runs BEFORE the controls are
+        // staged -- in a riding launch: while the combine role is still working on them (C2: 1.1 us
+        // of the dependent chain behind the hand-over; C3: 0.8 us of the first tile)
+        lane_start(std::integral_constant<int, 3>(), dps1, dvs0, dps, dvs);
+        if constexpr (FIRST) {
+            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTs, TA);
+            __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
+            MPPI_PK_STAMP(2);
+            // the nominal trajectory's state at the lane's first step, once per block
+            lane_start(std::integral_constant<int, 1>(), dps1, dvs0, dps_nom, dvs_nom);
+        } else {
+            MPPI_PK_STAMP(2);
+        }
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            dps[i] = fmaf(P.sp[i], dps[i], dps_nom[i]);
+            dvs[i] = fmaf(P.sv[i], dvs[i], dvs_nom[i]);
+        }
+#else
+        if constexpr (FIRST) {
+            if constexpr (RIDE) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTs, TA);
+            __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
+        }
+        MPPI_PK_STAMP(2);
 #if MPPI_PK_NOMINAL
         if constexpr (FIRST)    // the nominal trajectory's state at the lane's first step
             lane_start(std::integral_constant<int, 1>(), dps1, dvs0, dps_nom, dvs_nom);
         lane_start(std::integral_constant<int, 2>(), dps_nom, dvs_nom, dps, dvs);
 #else
         lane_start(std::integral_constant<int, 0>(), dps1, dvs0, dps, dvs);
+#endif
 #endif
         MPPI_PK_STAMP(3);
         float4 unext[BPG];
@@ -738,6 +765,29 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 
     // ---- the block's partial: the four waves' running sums meet here, once ------------------------
     //      M = min M_w, r_w = exp(-(M_w - M)/lambda), S = sum r_w S_w, N = sum r_w N_w
+    // First every WAVE adds up its own TPW trajectories, block by block, in trajectory order -- no
+    // barrier needed (its own LDS rows, its own instruction stream), so a wave that is done early
+    // does it while the others still compute, and all 256 threads share the gathers -- and leaves
+    // the sum where trajectory 0's block sat.  (Round 2 let thread m gather all 4 x TPW slots of
+    // block m behind the barrier: one or two waves walking 20 computed addresses each, 1.9-2.3 us
+    // per block at any size -- profiles/r03_trace_regions.txt "merge + partial store".)
+    if (Mw < INFINITY) {                    // (wave-uniform) a wave that saw nothing wrote nothing
+        __builtin_amdgcn_wave_barrier();
+        float4* const wbuf = buf + wave * NQ * kPkRow;
+        for (int m = lane; m < NBT; m += 64) {
+            const int r = m / BPG, b = m - r * BPG;          // group and block of the trajectory
+            const int ln0 = r / NG;
+            float4* const dst = wbuf + ((r - ln0 * NG) * BPG + b) * kPkRow + ln0;
+            float4 acc = *dst;                                // trajectory 0
+            for (int jj = 1; jj < TPW; ++jj) {
+                const int sl = jj * NGT + r;
+                const int ln = sl / NG;
+                const float4 v = wbuf[((sl - ln * NG) * BPG + b) * kPkRow + ln];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *dst = acc;
+        }
+    }
     if (lane == 0) {
         misc[wave] = Mw;
         misc[4 + wave] = Sw;
@@ -753,42 +803,19 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             rw[w] = (misc[w] < INFINITY) ? expf(-inv_lambda * (misc[w] - M)) : 0.0f;
             S = fmaf(rw[w], misc[4 + w], S);
         }
-        // thread m adds Philox block m of the horizon over the 4 waves x TPW trajectories, in that
-        // order, five trajectories of all four waves (20 loads) in flight at a time
+        // thread m: Philox block m of the horizon over the 4 waves, in wave order
         float4* Nout = reinterpret_cast<float4*>(g.part_N + (size_t)bid * Nrow);
         for (int m = threadIdx.x; m < NBT; m += kRolloutThreads) {
-            const int r = m / BPG, b = m - r * BPG;          // group and block of the trajectory
-            float4 acc[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int jj = 0; jj < TPW; jj += 5) {
-                float4 v[4][5];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-#pragma unroll
-                    for (int x = 0; x < 5; ++x) {
-                        v[w][x] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (jj + x < TPW && rw[w] != 0.0f) {  // (block-uniform; a wave that saw
-                            const int sl = (jj + x) * NGT + r; //  nothing never wrote its slots)
-                            const int ln = sl / NG;
-                            v[w][x] = buf[(w * NQ + (sl - ln * NG) * BPG + b) * kPkRow + ln];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-#pragma unroll
-                    for (int x = 0; x < 5; ++x) {
-                        acc[w].x += v[w][x].x; acc[w].y += v[w][x].y;
-                        acc[w].z += v[w][x].z; acc[w].w += v[w][x].w;
-                    }
-                }
-            }
+            const int r = m / BPG, b = m - r * BPG;
+            const int ln0 = r / NG;
+            const int off = ((r - ln0 * NG) * BPG + b) * kPkRow + ln0;
             float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                tot.x = fmaf(rw[w], acc[w].x, tot.x); tot.y = fmaf(rw[w], acc[w].y, tot.y);
-                tot.z = fmaf(rw[w], acc[w].z, tot.z); tot.w = fmaf(rw[w], acc[w].w, tot.w);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rw[w] != 0.0f) a = buf[w * NQ * kPkRow + off];      // (block-uniform)
+                tot.x = fmaf(rw[w], a.x, tot.x); tot.y = fmaf(rw[w], a.y, tot.y);
+                tot.z = fmaf(rw[w], a.z, tot.z); tot.w = fmaf(rw[w], a.w, tot.w);
             }
             Nout[m] = tot;
         }

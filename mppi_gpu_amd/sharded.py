@@ -11,13 +11,17 @@ after which every rank combines the G partials in rank order (bitwise identical 
     beta = min beta_g, r_g = exp(-(beta_g-beta)/lambda), nabla = sum r_g S_g,
     U += sum r_g N_g / nabla, then the shift.
 Two transports carry it, with identical results:
+    "collective"  (default) rank-local combine, ONE RCCL all-gather over xGMI, final combine:
+                  three launches.  What BASELINE.json's north_star names.
     "direct"      the rank-local combine kernel stores the partial straight into every rank's
                   inbox over xGMI (hipIpc-mapped uncached memory, 8-byte {value, tag} words) and
                   polls its own inbox: rollout + ONE launch per solve, no collective library on
-                  the data path (torch.distributed only hands the ipc handles round once);
-    "collective"  rank-local combine, RCCL all-gather, final combine: three launches.
-"auto" opens the direct exchange, checks on the first memcpy_set_data that one solve through it
-reproduces the collective's bits on every rank, and otherwise stays on the collective.
+                  the data path (torch.distributed only hands the ipc handles round once).
+                  Fewer launches and no collective latency, but it leans on peer-mapped memory.
+"auto" (what bench.py asks for) opens the direct exchange, checks on the first memcpy_set_data that
+one solve through it reproduces the collective's bits on every rank, and otherwise stays on the
+collective; the verdict is in `.validated`.  (A C++ host that is ONE process uses
+include/point_mass_sharded.hpp instead: the same two transports without torch.)
 The reference has no multi-GPU path; this is new.
 """
 from . import PointMassModel
@@ -43,7 +47,7 @@ class ShardedPointMassModel:
     the two GPU entry points; production code never passes them."""
 
     def __init__(self, nb_sim_global, steps, dt, state_dim, act_dim, group=None,
-                 engine_factory=None, tensor_factory=None, transport="auto"):
+                 engine_factory=None, tensor_factory=None, transport="collective"):
         if transport not in ("auto", "direct", "collective"):
             raise ValueError("transport must be auto, direct or collective")
         import torch

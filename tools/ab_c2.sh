@@ -1,4 +1,4 @@
-run() { python bench.py "$@" --no-cpu-baseline 2>/dev/null | python -c "
+run() { python bench.py "$@" --no-cpu-baseline --no-pmc --no-extra 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('  ms_per_step',round(d['ms_per_step']*1e3,2),'us kernel',round(d['roofline']['kernel_ms']*1e3,2),'combine',round(d['roofline']['combine_kernel_ms']*1e3,2), d['config']['launches_in_timed_region'], 'lat', d.get('latency',{}).get('blocking_get_act_ms'))"; }

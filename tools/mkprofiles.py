@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Turn what tools/r2_profiles.sh left under gpurun_out/ into the committed summaries under
-profiles/ (round 2): kernel-trace stats, SQ counters per wave, traffic_r02.json, alu_r02.json,
-bench lines, parity table, micro-benchmark tables.  Run in the authoring container after the GPU
-call; no GPU needed."""
+"""Turn what tools/r3_profiles.sh (r2_profiles.sh for round 2) left under gpurun_out/ into the
+committed summaries under profiles/: kernel-trace stats, SQ counters per wave, traffic_rNN.json,
+alu_rNN.json, bench lines, parity table, micro-benchmark tables.  Run in the authoring container
+after the GPU call; no GPU needed.      python tools/mkprofiles.py [round, default 3]"""
 import csv
 import json
 import os
 import shutil
+import sys
+
+RND = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+R, RR = f"r{RND}", f"r{RND:02d}"            # gpurun_out tags / committed file prefix
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out")
@@ -14,11 +18,18 @@ DST = os.path.join(ROOT, "profiles")
 
 # (profile tag, bench workload key, kernel-name substring, roofline key suffix)
 KEYS = [
-    ("r2_c2", "c2:chunks=16:ride", "k_rollout_ride<2"),
-    ("r2_c2e", "c2:chunks=16:plain", "k_rollout_fused<2"),
-    ("r2_c2", "c2:combine_small", "k_combine_small"),
-    ("r2_c3", "c3:packed4:plain", "k_rollout_packed<3"),
-    ("r2_c3", "c3:combine_small", "k_combine_small"),
+    (f"{R}_c2", "c2:chunks=16:ride", "k_rollout_ride<2"),
+    (f"{R}_c2e", "c2:chunks=16:plain", "k_rollout_fused<2"),
+    (f"{R}_c2", "c2:combine_small", "k_combine_small"),
+    (f"{R}_c3", "c3:packed4:plain", "k_rollout_packed<3"),
+    (f"{R}_c3", "c3:combine_small", "k_combine_small"),
+] if RND == 2 else [
+    (f"{R}_c2", "c2:chunks=16:ride", "k_rollout_ride<2"),
+    (f"{R}_c2e", "c2:chunks=16:plain", "k_rollout_fused<2"),
+    (f"{R}_c2e", "c2:combine", "k_combine<"),
+    (f"{R}_c3", "c3:packed4:ride", "k_rollout_packed_ride<3"),
+    (f"{R}_c3e", "c3:packed4:plain", "k_rollout_packed<3"),
+    (f"{R}_c3e", "c3:combine", "k_combine<"),
 ]
 # issue cost of a wave64 instruction in SIMD cycles at the nominal 2.4 GHz, measured with
 # tools/ubench_issue on MI355X at >= 4 waves per SIMD and ILP >= 2 (profiles/r02_ubench_issue.txt)
@@ -94,13 +105,13 @@ def main():
                         "mul_f32": round(v["SQ_INSTS_VALU_MUL_F32"]),
                         "issue_cycles_model": round(cyc),
                         "counter": busy}}
-    json.dump(traffic, open(os.path.join(DST, "traffic_r02.json"), "w"), indent=1)
-    json.dump(alu, open(os.path.join(DST, "alu_r02.json"), "w"), indent=1)
-    for tag in ("c2", "c2e", "c3", "c4"):
-        shutil.copy(os.path.join(SRC, "prof", f"r2_{tag}_stats.csv"),
-                    os.path.join(DST, f"r02_{tag}_kernel_stats.csv"))
-    for tag in ("c2", "c2e", "c3"):
-        shutil.copy(os.path.join(SRC, "prof", f"r2_{tag}_pmc.txt"), os.path.join(DST, f"r02_{tag}_pmc_sq.txt"))
+    json.dump(traffic, open(os.path.join(DST, f"traffic_{RR}.json"), "w"), indent=1)
+    json.dump(alu, open(os.path.join(DST, f"alu_{RR}.json"), "w"), indent=1)
+    for tag in ("c2", "c2e", "c3", "c4") + (("c3e",) if RND >= 3 else ()):
+        shutil.copy(os.path.join(SRC, "prof", f"{R}_{tag}_stats.csv"),
+                    os.path.join(DST, f"{RR}_{tag}_kernel_stats.csv"))
+    for tag in ("c2", "c2e", "c3") + (("c3e",) if RND >= 3 else ()):
+        shutil.copy(os.path.join(SRC, "prof", f"{R}_{tag}_pmc.txt"), os.path.join(DST, f"{RR}_{tag}_pmc_sq.txt"))
     def refresh(roof, key):
         # bench.py filled the counter-derived fields from the summaries committed BEFORE this run:
         # put this run's own (same box, same call) in their place
@@ -115,20 +126,29 @@ def main():
         if t:
             roof["traffic"] = t["hbm_bytes_per_launch"]
 
-    for f in ("bench_c2", "bench_c3", "bench_c4shard", "bench_c4full", "bench_c1", "bench_c2_sharded_1rank"):
-        line = open(os.path.join(SRC, "r2", f + ".json")).read().strip().splitlines()[-1]
+    benches = ["bench_c2", "bench_c3", "bench_c4shard", "bench_c4full", "bench_c1", "bench_c2_sharded_1rank"]
+    if RND >= 3:
+        benches.append("bench_c2_driverlike")
+    for f in benches:
+        line = open(os.path.join(SRC, R, f + ".json")).read().strip().splitlines()[-1]
         d = json.loads(line)
-        if f == "bench_c2":
-            refresh(d.get("roofline"), "c2:chunks=16:ride")
-            refresh(((d.get("extra") or {}).get("c3") or {}).get("roofline"), "c3:packed4:plain")
-        if f == "bench_c3":
-            refresh(d.get("roofline"), "c3:packed4:plain")
-        json.dump(d, open(os.path.join(DST, f"r02_{f}.json"), "w"), indent=1)
-    for f in ("ubench_issue.txt", "ubench_noise.txt", "latency_probe.txt"):
-        txt = [l for l in open(os.path.join(SRC, "r2", f)).read().splitlines() if "warning" not in l]
-        open(os.path.join(DST, "r02_" + f), "w").write("\n".join(txt) + "\n")
-    if os.path.exists(os.path.join(SRC, "parity_r02.json")):
-        shutil.copy(os.path.join(SRC, "parity_r02.json"), os.path.join(DST, "parity_r02.json"))
+        if RND == 2:
+            # round 2's bench.py quoted the counters of the summaries committed BEFORE the run
+            if f == "bench_c2":
+                refresh(d.get("roofline"), "c2:chunks=16:ride")
+                refresh(((d.get("extra") or {}).get("c3") or {}).get("roofline"), "c3:packed4:plain")
+            if f == "bench_c3":
+                refresh(d.get("roofline"), "c3:packed4:plain")
+        # (round 3's bench.py measures traffic / alu / rocprof duration itself, in child passes)
+        json.dump(d, open(os.path.join(DST, f"{RR}_{f}.json"), "w"), indent=1)
+    extra_txt = ["ubench_issue.txt", "ubench_noise.txt", "latency_probe.txt"] if RND == 2 else \
+                ["latency_probe.txt", "sweep_cost_error.txt", "lambda_speed.txt"]
+    for f in extra_txt:
+        txt = [l for l in open(os.path.join(SRC, R, f)).read().splitlines()
+               if "warning" not in l and "amdgpu.ids" not in l]
+        open(os.path.join(DST, f"{RR}_" + f), "w").write("\n".join(txt) + "\n")
+    if os.path.exists(os.path.join(SRC, f"parity_{RR}.json")):
+        shutil.copy(os.path.join(SRC, f"parity_{RR}.json"), os.path.join(DST, f"parity_{RR}.json"))
     for k, v in alu["entries"].items():
         print(k, v["kernel_ms_rocprof"], v["alu"]["achieved"])
     for k, v in traffic["entries"].items():

@@ -1,0 +1,29 @@
+#!/bin/bash
+# round-3 profile set, one box: kernel-trace stats, SQ counters, HBM traffic and VALU counters of
+# the bench workloads (C2 default = riding launch, C2 eager = plain rollout + combine, C3 default =
+# riding packed launch, C3 eager, C4 shard), plus the bench lines themselves.
+# Everything lands in gpurun_out/prof/ and gpurun_out/r3/; tools/mkprofiles.py 3 turns it into profiles/.
+set -o pipefail
+mkdir -p gpurun_out/prof gpurun_out/r3
+for cfg in "c2 --workload c2" "c2e --workload c2 --pipeline 1" "c3 --workload c3" "c3e --workload c3 --pipeline 1" "c4 --workload c4"; do
+  set -- $cfg; tag=r3_$1; shift
+  echo "== $tag kt"; bash tools/kt.sh $tag --no-pmc --no-extra --no-latency "$@" | tail -5
+done
+for cfg in "c2 --workload c2" "c2e --workload c2 --pipeline 1" "c3 --workload c3" "c3e --workload c3 --pipeline 1"; do
+  set -- $cfg; tag=r3_$1; shift
+  echo "== $tag traffic"; bash tools/traffic.sh $tag --no-pmc --no-extra --no-latency "$@" | tail -3
+  echo "== $tag alu"; bash tools/alu.sh $tag --no-pmc --no-extra --no-latency "$@" | tail -3
+  echo "== $tag pmc"; bash tools/pmc.sh $tag --no-pmc --no-extra --no-latency "$@" | tail -3
+done
+echo "== bench lines"
+python bench.py > gpurun_out/r3/bench_c2.json 2> gpurun_out/r3/bench_c2.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3/bench_c2_driverlike.json 2> gpurun_out/r3/bench_c2_driverlike.err
+python bench.py --workload c3 > gpurun_out/r3/bench_c3.json 2> gpurun_out/r3/bench_c3.err
+python bench.py --workload c4 --no-cpu-baseline > gpurun_out/r3/bench_c4shard.json 2>/dev/null
+python bench.py --workload c4full --no-cpu-baseline --steps 300 --warmup 30 > gpurun_out/r3/bench_c4full.json 2>/dev/null
+python bench.py --workload c1 --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c1.json 2>/dev/null
+python bench.py --force-sharded --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c2_sharded_1rank.json 2>gpurun_out/r3/bench_fs.err
+for cfg in "2 10000 200 2000" "3 100000 200 500" "1 100 50 2000"; do timeout -k 10 120 tools/latency_probe $cfg; done > gpurun_out/r3/latency_probe.txt
+python tools/sweep_cost_error.py > gpurun_out/r3/sweep_cost_error.txt 2>/dev/null
+python tools/lambda_speed.py > gpurun_out/r3/lambda_speed.txt 2>/dev/null
+ls gpurun_out/r3 gpurun_out/prof | head -60
