@@ -45,6 +45,10 @@ WORKLOADS = {
     "c4": (3, 125_000, 200, "point_mass3d K=1e6/8 per GPU T=200 (BASELINE configs[3] shard)"),
     "c1": (1, 100, 50, "point_mass1d K=100 T=50 (BASELINE configs[0] shape, on the GPU)"),
     "floor": (2, 10_000, 8, "launch-floor probe: 2-D K=1e4 T=8 (not a BASELINE config)"),
+    # the reference's SHIPPED configs (config/point_mass{1,2,3}d.yaml: samples 3000, horizon 50)
+    "s1": (1, 3000, 50, "point_mass1d.yaml as shipped: K=3000 T=50"),
+    "s2": (2, 3000, 50, "point_mass2d.yaml as shipped: K=3000 T=50"),
+    "s3": (3, 3000, 50, "point_mass3d.yaml as shipped: K=3000 T=50"),
     "c4full": (3, 1_000_000, 200, "point_mass3d K=1e6 T=200 on ONE GPU (BASELINE configs[3] unsharded)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
@@ -255,10 +259,13 @@ def pmc_traffic_live(workload, kernel_sub, extra_args=()):
             "dispatches": n}, None
 
 
-def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=()):
+def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=(), steps=2000):
     """Mean duration of the kernel by `rocprofv3 --kernel-trace --stats` over a child run of this
-    command (200 solves behind the clock ramp; no counters): what the committed
-    profiles/*_kernel_stats.csv hold, measured NOW.  (ms, calls) or (None, reason)."""
+    command (no counters): what the committed profiles/*_kernel_stats.csv hold, measured NOW.
+    `steps` is chosen by the caller so that the run lasts ~0.25 s: the mean of --stats covers EVERY
+    dispatch of the process, and the first hundred of a process run at rising clocks (C3: 83 us
+    against 65 at steady state, tools/kt_gaps.sh) -- a short profiled run reads 5-7 % slow.
+    (ms, calls) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -270,7 +277,7 @@ def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=()):
     tmp = tempfile.mkdtemp(prefix="mppi_kt_", dir="/tmp")
     try:
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "--",
-               sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "200",
+               sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps),
                "--warmup", "20", "--no-cpu-baseline", "--no-events", "--no-pmc", "--no-extra",
                "--no-latency", *extra_args]
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True,
@@ -293,7 +300,7 @@ def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=()):
 ISSUE_COST = {"INT64": 6.3, "TRANS_F32": 8.4, "BITOP3": 4.2, "OTHER": 2.3}
 
 
-def pmc_alu_live(workload, kernel_sub, extra_args=()):
+def pmc_alu_live(workload, kernel_sub, extra_args=(), kernel_ms=None):
     """The VALU side of the roofline, measured NOW: instruction counts by class, the counter-based
     VALU busy (rocprof's VALUBusy = SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE) and the
     issue-cycle model (count x measured issue cycles per class / SIMD cycles of the launch)."""
@@ -303,6 +310,9 @@ def pmc_alu_live(workload, kernel_sub, extra_args=()):
     v, dur_us, n = pmc_child_passes(workload, kernel_sub, sets, extra_args)
     if v is None:
         return None, dur_us
+    # the issue-cycle model is priced against the STEADY-STATE duration of the launch (this run's
+    # event stamps): the 25 dispatches of a counter pass run at the clocks of a cold process
+    model_us = kernel_ms * 1e3 if kernel_ms else dur_us
     n_simd, f_nom = 1024, 2.4e9
     n_all, n64, ntr = v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU_INT64"], v["SQ_INSTS_VALU_TRANS_F32"]
     nb3 = n64                       # one v_bitop3_b32 per v_mad_u64_u32 (two of each per Philox round)
@@ -311,14 +321,15 @@ def pmc_alu_live(workload, kernel_sub, extra_args=()):
     gui = v["GRBM_GUI_ACTIVE"]
     inst = 8.0 if dur_us > 0 and gui / (dur_us * 1e-6) > 6e9 else 1.0    # summed over the 8 XCDs, or not
     gui_cycles = gui / inst
-    return {"bound": "valu", "achieved": round(cyc / (n_simd * dur_us * 1e-6 * f_nom), 4), "peak": 1.0,
+    return {"bound": "valu", "achieved": round(cyc / (n_simd * model_us * 1e-6 * f_nom), 4), "peak": 1.0,
             "unit": "fraction of the launch's VALU issue cycles (issue-cycle model)",
             "valu_busy_counter": round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / n_simd / gui_cycles, 4),
             "valu_instructions_per_launch": round(n_all), "v_mad_u64_u32": round(n64),
             "transcendental": round(ntr), "fma_f32": round(v["SQ_INSTS_VALU_FMA_F32"]),
             "add_f32": round(v["SQ_INSTS_VALU_ADD_F32"]), "mul_f32": round(v["SQ_INSTS_VALU_MUL_F32"]),
             "wait_any_fraction_of_wave_cycles": round(v["SQ_WAIT_ANY"] / max(1.0, v["SQ_WAVE_CYCLES"]), 4),
-            "kernel_us_in_these_passes": round(dur_us, 3), "dispatches": n,
+            "kernel_us_in_these_passes": round(dur_us, 3), "kernel_us_model": round(model_us, 3),
+            "dispatches": n,
             "source": "measured in this run: three child passes of this command under rocprofv3 "
                       "--kernel-trace --pmc (SQ instruction counters; SQ_ACTIVE_INST_VALU; "
                       "GRBM_GUI_ACTIVE), per-class issue costs from profiles/r02_ubench_issue.txt"}, None
@@ -353,12 +364,14 @@ def attach_live_traffic(roof, workload, kernel_sub, extra_args=()):
     roof["traffic_source"] = ("measured in this run: two child passes of this command under rocprofv3 "
                               "--kernel-trace --pmc (FETCH_SIZE x2 + WRITE_SIZE, one counter per pass), "
                               "mean over %d dispatches of %s" % (t["dispatches"], kernel_sub))
-    a, why = pmc_alu_live(workload, kernel_sub, extra_args)
+    a, why = pmc_alu_live(workload, kernel_sub, extra_args, kernel_ms=roof.get("kernel_ms"))
     if a is None:
         roof["alu_live_error"] = why
     else:
         roof["alu"] = a
-    km, calls = rocprof_kernel_ms_live(workload, kernel_sub, extra_args)
+    k_ms_ev = roof.get("kernel_ms") or 0.05
+    km, calls = rocprof_kernel_ms_live(workload, kernel_sub, extra_args,
+                                       steps=int(min(20000, max(400, 250.0 / k_ms_ev))))
     if km is None:
         roof["kernel_ms_rocprof_error"] = calls
     else:

@@ -6,7 +6,9 @@
 set -o pipefail
 mkdir -p gpurun_out/prof gpurun_out/r3
 for cfg in "c2 --workload c2" "c2e --workload c2 --pipeline 1" "c3 --workload c3" "c3e --workload c3 --pipeline 1" "c4 --workload c4"; do
-  set -- $cfg; tag=r3_$1; shift
+  set -- $cfg; tag=r3_$1
+  case $1 in c2|c2e) export KT_STEPS=20000;; *) export KT_STEPS=4000;; esac
+  shift
   echo "== $tag kt"; bash tools/kt.sh $tag --no-pmc --no-extra --no-latency "$@" | tail -5
 done
 for cfg in "c2 --workload c2" "c2e --workload c2 --pipeline 1" "c3 --workload c3" "c3e --workload c3 --pipeline 1"; do
