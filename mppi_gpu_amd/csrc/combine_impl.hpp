@@ -64,6 +64,11 @@ __device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigne
 #ifndef MPPI_FIN_SCOPE_AGENT
 #define MPPI_FIN_SCOPE_AGENT 0     // experiment: agent-scope stores for words that stay on this GPU
 #endif
+#ifndef MPPI_FIN_COPIES
+#define MPPI_FIN_COPIES 1          // experiment: one copy of the finished-control words per XCD
+#endif
+// the finished control n, for the rollout blocks of a riding launch to pick up
+__device__ __forceinline__ void publish_fin(const CombineArgs& a, int n, float unew);
 // a tagged word read only by blocks of THIS device (row-split sums, finished controls)
 __device__ __forceinline__ void ll_store_local(unsigned long long* p, float v, unsigned int tag)
 {
@@ -73,6 +78,13 @@ __device__ __forceinline__ void ll_store_local(unsigned long long* p, float v, u
 #else
     ll_store(p, v, tag);
 #endif
+}
+
+__device__ __forceinline__ void publish_fin(const CombineArgs& a, int n, float unew)
+{
+#pragma unroll
+    for (int cpy = 0; cpy < MPPI_FIN_COPIES; ++cpy)
+        ll_store_local(a.slab_tag + (size_t)(kMaxSmallSplits + cpy) * a.TA + n, unew, a.tag);
 }
 
 // Has a block of some launch of this engine already given up waiting?  (the device watchdog
@@ -163,7 +175,7 @@ __device__ __forceinline__ void finish_columns(const CombineArgs& a, int cb, int
     if (n < a.TA) {
         const float unew = updated_control(a, n, uin, tot, nabla);
         // (the tagged word first: a rollout block of a riding launch is waiting for it)
-        if (a.slab_tag) ll_store_local(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        if (a.slab_tag) publish_fin(a, n, unew);
         publish_control(a, n, unew);
     }
     if (cb == 0 && tid == 0) {
@@ -178,7 +190,7 @@ __device__ __forceinline__ void combine_apply(const CombineArgs& a, int n, float
     if (a.final_mode) {
         const float unew = updated_control(a, n, uin, tot, nabla);
         // (the tagged word first: a rollout block of a riding launch is waiting for it)
-        if (a.slab_tag) ll_store_local(a.slab_tag + (size_t)kMaxSmallSplits * a.TA + n, unew, a.tag);
+        if (a.slab_tag) publish_fin(a, n, unew);
         publish_control(a, n, unew);
     } else {
         a.partial_out[2 + n] = tot;
@@ -200,7 +212,13 @@ __device__ __forceinline__ void ride_fetch_controls(const RolloutArgs& g, const 
     bool timed_out = false;
     float* uflat = reinterpret_cast<float*>(ulds);
     float* ucflat = reinterpret_cast<float*>(uclds);
+#if MPPI_FIN_COPIES > 1
+    // (XCC_ID: hardware register 20 of gfx950; blocks are dealt round robin over the 8 XCDs)
+    const unsigned long long* fin_p =
+        g.fin_tag + (size_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) % MPPI_FIN_COPIES) * TA;
+#else
     const unsigned long long* fin_p = g.fin_tag;
+#endif
     const unsigned int tag_want = d.c.tag;
     constexpr int kBatch = 4;      // words in flight per thread: one round trip, not four
     for (int base = threadIdx.x; base < n_blocks * 4; base += kBatch * kRolloutThreads) {

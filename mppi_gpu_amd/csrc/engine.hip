@@ -850,7 +850,7 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     *e->h_err = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&e->h_err_dev, e->h_err, 0));
     {
-        const size_t words = (size_t)(mppi::kMaxSmallSplits + 1) * e->TA;
+        const size_t words = (size_t)(mppi::kMaxSmallSplits + 8) * e->TA;   // (+ 8: MPPI_FIN_COPIES experiments)
         HIPCHK(hipMalloc(&e->d_slab_tag, words * sizeof(unsigned long long)));
         HIPCHK(hipMemset(e->d_slab_tag, 0, words * sizeof(unsigned long long)));
     }

@@ -12,6 +12,9 @@
 #ifndef MPPI_FUSED_DIRECT_FOLD
 #define MPPI_FUSED_DIRECT_FOLD 1   // the block's last tile folds straight into the global partial
 #endif
+#ifndef MPPI_FUSED_LATE_STORE
+#define MPPI_FUSED_LATE_STORE 0    // riding launch, first tile: the noise stores are issued AFTER the
+#endif                             // controls have arrived (the polls do not queue behind them)
 #ifndef MPPI_FUSED_PRIO
 #define MPPI_FUSED_PRIO 2      // s_setprio of the passes after the Philox pass (which runs at 0)
 #endif
@@ -187,7 +190,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                         box_muller_hw(r.z, r.w, z[2], z[3]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
-                        if (store_e && c * nq + q < NBT) {   // blocks past the horizon are not stored
+                        if (store_e && c * nq + q < NBT &&   // blocks past the horizon are not stored
+                            !(MPPI_FUSED_LATE_STORE && RIDE && first)) {
                             // Write-through store (sc0 sc1): E is not read again by this
                             // launch, and what a plain store leaves dirty in the XCD L2s -- all
                             // 16 MB at C2 -- is written back at the END of the kernel, where
@@ -218,6 +222,28 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         if (first) {
             if constexpr (deferred) ride_fetch_controls<A>(g, d, lambda, ulds, uclds, NBTp, TA);
             __syncthreads();             // U and lambda*inv_s*U are in LDS from here on
+#if MPPI_FUSED_LATE_STORE
+            if constexpr (RIDE && SAMPLE) {
+                if (store_e) {
+#pragma unroll
+                    for (int gi = 0; gi < NG; ++gi) {
+                        if (gi < ngs) {
+#pragma unroll
+                            for (int j = 0; j < BPG; ++j) {
+                                const int q = gi * BPG + j;
+                                if (c * nq + q < NBT) {
+                                    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                                    const v4u val = {__float_as_uint(e[q * 4]), __float_as_uint(e[q * 4 + 1]),
+                                                     __float_as_uint(e[q * 4 + 2]), __float_as_uint(e[q * 4 + 3])};
+                                    __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                                           17 /* sc0 | sc1 */);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#endif
         }
         if (first) MPPI_STAMP(2);
 
