@@ -27,8 +27,9 @@
  *     1e-5 * max(|U|, sigma) in the controls wherever more than a handful of samples carry
  *     weight.  A cost weight of exactly 0 is carried as the scale 2^-60: a problem whose weights
  *     are ALL zero reports path costs of ~1e-36 instead of 0 (the controls are unaffected).
- *     Horizons are bounded by the 64 KiB of LDS a block uses: about T * act_dim <= 2000
- *     (MPPI_EINVAL beyond).
+ *     Horizons are bounded by the LDS one block may use on gfx950 (160 KiB: about
+ *     T * act_dim <= 5000; beyond 64 KiB fewer blocks share a CU) and by the 64 lanes x groups per
+ *     lane a trajectory can be spread over (MPPI_EINVAL beyond).
  */
 #ifndef MPPI_GPU_AMD_H_
 #define MPPI_GPU_AMD_H_

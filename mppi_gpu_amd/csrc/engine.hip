@@ -259,7 +259,7 @@ int ensure_geometry(mppi_engine_t* e)
         if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
             packed = false;
         const bool pk_fits = pk_NG > 0 &&
-                             mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) <= 64 * 1024;
+                             mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) <= mppi::kMaxLdsBytes;
         if (packed && e->user_packing <= 0 && !pk_fits)
             packed = false;          // horizon too long for the LDS slots: row-aligned kernel
         if (!packed && e->user_packing == 0 && pk_fits) {
@@ -267,7 +267,7 @@ int ensure_geometry(mppi_engine_t* e)
             // (the per-wave weighted-noise rows grow with T*A) may still fit the packed one
             const int nq_row = ng * e->BPG;
             const int NBTp_row = (C * nq_row > e->NBT) ? C * nq_row : e->NBT;
-            if (mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4) > 64 * 1024) packed = true;
+            if (mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4) > mppi::kMaxLdsBytes) packed = true;
         }
     }
     if (packed) {
@@ -340,8 +340,8 @@ int ensure_geometry(mppi_engine_t* e)
     const int grid = (int)(ntb < max_blocks ? ntb : max_blocks);
 
     const size_t lds = lds_need;
-    if (lds > 64 * 1024)
-        return fail(MPPI_EINVAL, "LDS need %zu B exceeds 64 KiB (T=%d A=%d C=%d)", lds, e->T, e->A,
+    if (lds > mppi::kMaxLdsBytes)
+        return fail(MPPI_EINVAL, "LDS need %zu B exceeds 160 KiB (T=%d A=%d C=%d)", lds, e->T, e->A,
                     C);
 
     const size_t need = (size_t)ntb * 4 * nq * 64 * 4;      // 4 wavefront tiles per tile group

@@ -331,9 +331,17 @@ hipError_t launch_regen_noise(int A, float* E_ktA, int K, int T, unsigned long l
                               unsigned long long solve_idx, long long k_offset, const float* sigma4,
                               hipStream_t st);
 
+// LDS one block may use: gfx950 has 160 KB per CU and lets one workgroup have all of it
+// (tools/lds_probe.hip); a launch beyond the 64 KB every HIP device grants opts in per kernel.
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+constexpr size_t kDefaultLdsBytes = 64 * 1024;
+
 // launch with or without dispatch timing
 #define MPPI_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                       \
     do {                                                                                         \
+        if ((size_t)(lds) > mppi::kDefaultLdsBytes)                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds));   \
         if ((tm).start && (tm).stop)                                                             \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, st, (tm).start, (tm).stop, 0,        \
                                   __VA_ARGS__);                                                  \

@@ -899,6 +899,8 @@ hipError_t launch_packed_t(bool sample, int grid, const RolloutArgs& a, const De
     DeferredCombine dd = d;
     const dim3 g(grid + d.n_blocks), b(kRolloutThreads);
     const void* fn = packed_kernel<A, NG>(sample, ride, a.pk_nlast < Dim<A>::SG);
+    if (lds > kDefaultLdsBytes)
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* args[2] = {&h, &dd};          // (the plain kernel takes the first only)
     if (tm.start && tm.stop)
         return hipExtLaunchKernel(fn, g, b, args, lds, st, tm.start, tm.stop, 0);

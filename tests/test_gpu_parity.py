@@ -182,6 +182,10 @@ CASES = [
     (1, 300, 512),     # long horizons: the cost bar grows with T (cost_rtol)
     (1, 200, 1000),
     (3, 100, 512),
+    (3, 60, 1000),     # beyond 64 KiB of LDS per block (gfx950 grants a workgroup up to 160 KiB)
+    (2, 50, 2000),
+    (1, 40, 4000),
+    (4, 40, 1200),
 ]
 
 
@@ -240,6 +244,8 @@ PACKED_CASES = [
     (1, 200, 1000, 4, 0),
     (3, 100, 512, 4, 0),
     (2, 100, 1000, 8, 0),
+    (3, 60, 1000, 4, 0),       # 74 KiB of LDS per block
+    (3, 33, 1023, 4, 2),       # ... ragged, on a persistent grid
     # ragged horizons: the last group of a trajectory holds fewer steps than a group (masked)
     (3, 3000, 50, 4, 0),       # the reference's shipped config/point_mass3d.yaml: 12 groups + 2 steps
     (1, 513, 203, 4, 0),       # 50 groups + 3 steps
