@@ -33,4 +33,5 @@ g++ -O2 -std=c++17 -I include apps/mppi_closed_loop.cpp -o apps/mppi_closed_loop
   apps/mppi_closed_loop --dims 2 --samples 10000 --horizon 200 --seconds 2 | grep -E "RESULT"; } > gpurun_out/r3/closed_loop.txt 2>&1
 python tools/sweep_cost_error.py > gpurun_out/r3/sweep_cost_error.txt 2>/dev/null
 python tools/lambda_speed.py > gpurun_out/r3/lambda_speed.txt 2>/dev/null
+{ timeout -k 10 300 python tools/soak_packed.py 5000; timeout -k 10 300 python tools/soak.py 50000 4; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r3/soak.txt
 ls gpurun_out/r3 gpurun_out/prof | head -60
