@@ -237,10 +237,10 @@ int mppi_kernel_ms(mppi_engine* e, int which, double* avg_ms, int* n_out);
 /* Launch geometry actually in use: chunks, blocks per chunk (nq), grid, block, strict. */
 int mppi_get_geometry(mppi_engine* e, int out[5]);
 /* Launches since mppi_create: out[0] rollout launches, out[1] those of them that carried the
- * previous solve's combine (pipeline mode 0: only launches that are short AND whose blocks --
- * rollout and combine role -- all fit the chip at once), out[2] combine launches on their own
- * (the 256-thread shape), out[3] blocks of the riding kernel the chip holds at once (occupancy
- * API x CUs; 0 = unknown, nothing rides). */
+ * previous solve's combine (pipeline mode 0; the row-aligned kernel: only launches that are short
+ * AND whose blocks -- rollout and combine role -- all fit the chip at once; the packed kernel: any
+ * launch), out[2] combine launches on their own (the 256-thread shape), out[3] blocks of the
+ * riding kernel the chip holds at once (occupancy API x CUs). */
 int mppi_get_launch_counts(mppi_engine* e, long long out[4]);
 
 /* ---- serial CPU controller ------------------------------------------------------------ */
