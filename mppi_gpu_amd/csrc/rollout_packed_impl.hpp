@@ -49,6 +49,9 @@
 #ifndef MPPI_PK_PRIO
 #define MPPI_PK_PRIO 2         // s_setprio of the latency-bound passes (the Philox pass runs at 0)
 #endif
+#ifndef MPPI_PK_PRIO_ALT
+#define MPPI_PK_PRIO_ALT 0     // experiment: the two blocks of a CU alternate a priority bonus per tile
+#endif
 #ifndef MPPI_PK_RACC3
 #define MPPI_PK_RACC3 1        // three cost accumulators per axis (shorter dependent chains)
 #endif
@@ -251,7 +254,14 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         // passes after it are chains of dependent instructions.  Left at equal priority the OLDER
         // of the two waves of a SIMD wins every arbitration: the first block of a CU ran its tiles
         // in 66 us, the second in 90 (the kernel's time).  Low priority here, high below.
-#if MPPI_PK_PRIO
+#if MPPI_PK_PRIO_ALT
+        // experiment: the two blocks of a CU take turns at the upper hand, tile by tile (at equal
+        // priority the OLDER wave of a SIMD wins every arbitration: the second block of every CU
+        // runs its tiles 9 % slower and, with as many tiles, sets the launch's duration)
+        const bool my_turn = (((tb - bid) / nblk + (bid >= (nblk >> 1) ? 1 : 0)) & 1) != 0;
+        if (my_turn) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#elif MPPI_PK_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         float e[NE];
@@ -302,7 +312,10 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
             }
         }
         MPPI_PK_STAMP(1);
-#if MPPI_PK_PRIO
+#if MPPI_PK_PRIO_ALT
+        if (my_turn) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
+#elif MPPI_PK_PRIO
         __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
 #endif
 
