@@ -186,6 +186,13 @@ int mppi_flush_async(mppi_engine* e);
 /* Wait for everything enqueued by this engine and copy the last action into next_act[A]. */
 int mppi_sync_act(mppi_engine* e, float* next_act);
 
+/* Wait for the ACTION of the newest enqueued solve only, the way mppi_get_act does: launch what is
+ * still held back, then poll the pinned {action bits, tag} words the combine kernel writes (no
+ * hipStreamSynchronize and its wake-up unless 300 us pass).  mppi_get_act = mppi_solve_async +
+ * mppi_wait_act; a host that drives several engines (include/mppi_gpu_amd_sharded.h) enqueues on
+ * all of them first and waits afterwards.  Later calls are stream-ordered behind the solve. */
+int mppi_wait_act(mppi_engine* e, float* next_act);
+
 /* Sharded solve (one engine per GPU, samples k_offset .. k_offset+nb_sim-1 of a global
  * batch).  Step 1 enqueues sampling, rollout and the rank-local reduction and writes
  * mppi_partial_len() floats [beta_g, S_g, N_g[T*A]] to the DEVICE buffer d_partial.

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mppi_solve_async": (C.c_int, [engine_p, C.c_void_p]),
     "mppi_flush_async": (C.c_int, [engine_p]),
     "mppi_sync_act": (C.c_int, [engine_p, c_float_p]),
+    "mppi_wait_act": (C.c_int, [engine_p, c_float_p]),
     "mppi_partial_len": (C.c_int, [engine_p]),
     "mppi_solve_local_async": (C.c_int, [engine_p, C.c_void_p, C.c_void_p]),
     "mppi_solve_finish_async": (C.c_int, [engine_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -145,6 +145,8 @@ struct mppi_engine {
     // direct peer exchange (mppi_xchg_*)
     int xg_rank = -1, xg_world = 0, xg_W = 0;
     bool xg_connected = false;
+    bool xg_peer_on_my_device = false;                 // a peer's inbox lives on THIS GPU (rehearsals,
+                                                       // GPU sharing): see enqueue_rollout
     unsigned long long* xg_inbox = nullptr;            // this rank's inbox (uncached device memory)
     std::vector<void*> xg_opened;                      // hipIpcOpenMemHandle mappings to close
     unsigned long long** d_xg_peers = nullptr;         // device table of the G inbox bases
@@ -668,7 +670,12 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         // combine-role blocks come first and hold their slots before a rollout block can wait for
         // them); the watchdog bounds the wait if that ever fails, and the engine then falls back to
         // stand-alone launches by itself (check_watchdog).
-        const bool ride_ok = e->packed ? (e->tune_ride_long != 0 || (short_launch && co_resident))
+        // (an EXCHANGE that rides makes the rollout blocks wait for the peers' words too: with a
+        //  peer on this very GPU -- rehearsals, GPU sharing -- a launch that fills the chip would
+        //  keep the peer's launch, which has to send them, from ever getting a slot)
+        const bool long_ok = e->tune_ride_long != 0 &&
+                             !(e->pending_mode == 2 && e->xg_peer_on_my_device);
+        const bool ride_ok = e->packed ? (long_ok || (short_launch && co_resident))
                                        : (short_launch && co_resident);
         if (!carry || e->strict || e->pending_stream != st || !ride_ok) {
             const hipStream_t was = e->pending_stream;
@@ -1022,6 +1029,13 @@ int mppi_get_act(mppi_engine* e, float* next_act)
     if (!e || !next_act) return fail(MPPI_EINVAL, "null argument");
     int rc = mppi_solve_async(e, nullptr);
     if (rc) return rc;
+    return mppi_wait_act(e, next_act);
+}
+
+int mppi_wait_act(mppi_engine* e, float* next_act)
+{
+    if (!e || !next_act) return fail(MPPI_EINVAL, "null argument");
+    int rc;
     if ((rc = flush_pending(e))) return rc;
     // The closed-loop call: poll the pinned words the combine kernel writes the action into
     // (8-byte {value, tag} stores) instead of sleeping in hipStreamSynchronize, whose wake-up
@@ -1411,6 +1425,21 @@ int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_pro
     }
     HIPCHK(hipMemcpy(e->d_xg_peers, tab.data(), mppi::kMaxRanks * sizeof(void*),
                      hipMemcpyHostToDevice));
+    {   // does a peer live on this very GPU?  (several shard engines or processes sharing a device:
+        // their riding launches wait for each other's words and must then fit the chip TOGETHER)
+        int my_dev = 0;
+        (void)hipGetDevice(&my_dev);
+        e->xg_peer_on_my_device = false;
+        for (int g = 0; g < e->xg_world; ++g) {
+            if (g == e->xg_rank) continue;
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, tab[g]) == hipSuccess) {
+                if (at.device == my_dev) e->xg_peer_on_my_device = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     e->xg_connected = true;
     e->args_valid = false;      // the riding rollout's watchdog outwaits the exchange time-out
     return MPPI_OK;

@@ -49,6 +49,14 @@
 #ifndef MPPI_PK_PRIO
 #define MPPI_PK_PRIO 2         // s_setprio of the latency-bound passes (the Philox pass runs at 0)
 #endif
+#ifndef MPPI_PK_SCAN_BRANCH
+#define MPPI_PK_SCAN_BRANCH 0  // experiment: the absorb test of the segmented scans as an exec-masked branch
+#endif
+#if MPPI_PK_SCAN_BRANCH
+#define MPPI_PK_NOFLATTEN() asm volatile("")   // (a volatile asm cannot be speculated: no if-conversion)
+#else
+#define MPPI_PK_NOFLATTEN() do { } while (0)
+#endif
 #ifndef MPPI_PK_PRIO_ALT
 #define MPPI_PK_PRIO_ALT 0     // experiment: the two blocks of a CU alternate a priority bonus per tile
 #endif
@@ -416,6 +424,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                         Vl[i] = GETF(Vz[i]);                                        \
                     }                                                               \
                     if (absorb & (BIT)) {                                           \
+                        MPPI_PK_NOFLATTEN();                                        \
                         _Pragma("unroll") for (int i = 0; i < A; ++i) {             \
                             Qz[i] = Ql[i] + Qz[i];                                  \
                             Vz[i] = Vl[i] + Vz[i];                                  \
@@ -663,7 +672,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
 #define MPPI_PK_CSUMQ(BIT, GETF)                                                    \
             {                                                                       \
                 const float cl = GETF(cz);                                          \
-                if (absorb & (BIT)) cz = cl + cz;                                   \
+                if (absorb & (BIT)) { MPPI_PK_NOFLATTEN(); cz = cl + cz; }         \
             }
             MPPI_PK_CSUMQ(1u, dpp<MPPI_ROW_SHR(1)>)
             MPPI_PK_CSUMQ(2u, dpp<MPPI_ROW_SHR(2)>)

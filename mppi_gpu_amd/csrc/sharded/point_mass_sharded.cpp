@@ -387,7 +387,7 @@ int mppi_sharded_get_u(mppi_sharded* c, float* u)
     });
 }
 
-int mppi_sharded_solve_async(mppi_sharded* c)
+static int solve_async_impl(mppi_sharded* c, bool flush_too)
 {
     if (!c) return fail(MPPI_EINVAL, "null controller");
     if (!c->data_set) return fail(MPPI_ESTATE, "solve before mppi_sharded_set_data");
@@ -395,8 +395,11 @@ int mppi_sharded_solve_async(mppi_sharded* c)
     int rc = MPPI_OK;
     switch (c->transport) {
     case MPPI_XPORT_DIRECT:
-        rc = c->run_all([](Shard& s) {
+        rc = c->run_all([flush_too](Shard& s) {
             ENG(s, mppi_solve_exchange_async(s.eng, s.stream));
+            // (a blocking get_act: launch the held-back exchange in the same hand-over -- every
+            //  shard must have launched its own before anybody waits)
+            if (flush_too) ENG(s, mppi_flush_async(s.eng));
             return (int)MPPI_OK;
         });
         break;
@@ -436,11 +439,13 @@ int mppi_sharded_solve_async(mppi_sharded* c)
     return MPPI_OK;
 }
 
-int mppi_sharded_sync_act(mppi_sharded* c, float* next_act)
+int mppi_sharded_solve_async(mppi_sharded* c) { return solve_async_impl(c, false); }
+
+static int sync_act_impl(mppi_sharded* c, float* next_act, bool flushed)
 {
     if (!c) return fail(MPPI_EINVAL, "null controller");
     int rc;
-    if (c->transport == MPPI_XPORT_DIRECT) {
+    if (c->transport == MPPI_XPORT_DIRECT && !flushed) {
         // a held-back exchange waits for the peers' words: every shard launches its own before
         // anybody waits (mppi_flush_async)
         rc = c->run_all([](Shard& s) {
@@ -449,8 +454,11 @@ int mppi_sharded_sync_act(mppi_sharded* c, float* next_act)
         });
         if (rc) return rc;
     }
-    rc = c->run_all([](Shard& s) {
-        ENG(s, mppi_sync_act(s.eng, s.act));
+    // a blocking get_act waits for the action words only (mppi_wait_act polls them: no
+    // hipStreamSynchronize wake-up); everything else is a full synchronisation
+    rc = c->run_all([flushed](Shard& s) {
+        if (flushed) ENG(s, mppi_wait_act(s.eng, s.act));
+        else ENG(s, mppi_sync_act(s.eng, s.act));
         return (int)MPPI_OK;
     });
     if (rc) return rc;
@@ -462,12 +470,14 @@ int mppi_sharded_sync_act(mppi_sharded* c, float* next_act)
     return MPPI_OK;
 }
 
+int mppi_sharded_sync_act(mppi_sharded* c, float* next_act) { return sync_act_impl(c, next_act, false); }
+
 int mppi_sharded_get_act(mppi_sharded* c, float* next_act)
 {
     if (!c || !next_act) return fail(MPPI_EINVAL, "null argument");
-    int rc = mppi_sharded_solve_async(c);
+    int rc = solve_async_impl(c, true);      // two hand-overs to the workers per call, not three
     if (rc) return rc;
-    return mppi_sharded_sync_act(c, next_act);
+    return sync_act_impl(c, next_act, true);
 }
 
 int mppi_sharded_get_inf(mppi_sharded* c, float* x_all, float* u, float* noise, float* cost,

@@ -1,15 +1,17 @@
 """Extended seeded sweep of the packed kernel against the oracle: the generator of
 tests/test_gpu_parity.py::test_packed_kernel_random_shapes_against_oracle with other seeds, 200 trials.
 Run from the repository root on a GPU box: python tools/sweep_packed.py
-Known to trip the tests' fixed cost bar (3e-6 relative): horizons of 430 steps and more, where the
-path costs of BOTH fused kernels agree with the oracle to 3.0-3.8e-6 (error grows with the number
-of steps; 2e-6 at the T = 200 of every BASELINE config), and a case with ALL cost weights zero
-(oracle cost exactly 0, device ~1e-36 from the 2^-60 stand-in scale).  The controls agree in all."""
+Round 2 found horizons of 430 steps and more above the then fixed cost bar of 3e-6 (3.0-3.8e-6 in
+BOTH fused kernels): the bar is a function of the horizon since round 3 (cost_rtol(T) =
+max(3e-6, 0.35 T 2^-24)).  Still expected to trip: a case with ALL cost weights zero (oracle cost
+exactly 0, device ~1e-36 from the 2^-60 stand-in scale; the controls agree).  With `ragged` as the
+first argument the horizons are NOT whole groups (T = groups * steps - 1 .. steps - 1)."""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import oracle_lib as ol
 import test_gpu_parity as tg
+RAGGED = len(sys.argv) > 1 and sys.argv[1] == "ragged"
 NGS = {1: [4], 2: [5, 8], 3: [4], 4: [10]}
 SGS = {1: 4, 2: 2, 3: 4, 4: 1}
 bad = 0
@@ -19,6 +21,8 @@ for seed in (11, 12, 13, 14):
         A = int(rng.integers(1, 5)); ngl = int(rng.choice(NGS[A]))
         ngt = int(rng.integers(ngl, min(64 * ngl, 140, 1000 // (SGS[A] * A)) + 1))
         T = ngt * SGS[A]
+        if RAGGED and SGS[A] > 1:
+            T -= int(rng.integers(1, SGS[A]))
         K = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1025, 2500, 7000]))
         lam = float(rng.choice([0.5, 1.0, 2.0]))
         c = ol.make_case(A, K, T, seed=9000 + 100 * seed + trial, u_scale=float(rng.choice([0.0, 0.05, 0.5])))
