@@ -45,6 +45,9 @@ WORKLOADS = {
     "c4": (3, 125_000, 200, "point_mass3d K=1e6/8 per GPU T=200 (BASELINE configs[3] shard)"),
     "c1": (1, 100, 50, "point_mass1d K=100 T=50 (BASELINE configs[0] shape, on the GPU)"),
     "floor": (2, 10_000, 8, "launch-floor probe: 2-D K=1e4 T=8 (not a BASELINE config)"),
+    # sweep points between config 3 and config 4 (where the noise no longer fits the 256 MB MALL)
+    "c3x2": (3, 200_000, 200, "point_mass3d K=2e5 T=200 (sweep point, not a BASELINE config)"),
+    "c3x4": (3, 400_000, 200, "point_mass3d K=4e5 T=200 (sweep point, not a BASELINE config)"),
     # the reference's SHIPPED configs (config/point_mass{1,2,3}d.yaml: samples 3000, horizon 50)
     "s1": (1, 3000, 50, "point_mass1d.yaml as shipped: K=3000 T=50"),
     "s2": (2, 3000, 50, "point_mass2d.yaml as shipped: K=3000 T=50"),

@@ -94,6 +94,7 @@ struct mppi_engine {
     int tune_combine_splits = 0;            // MPPI_COMBINE_SPLITS: row splits of the combine, 0 = auto
     int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
     int tune_ride_long = 1;                 // MPPI_RIDE_LONG: packed launches of any length carry it
+    int tune_store_mode = 0;                // MPPI_STORE_MODE: 1 write-through, 2 non-temporal noise stores (0 = by size)
     long long resident_ride = 0;            // blocks of the riding kernel variant the chip holds at once
     long long n_rollout_launches = 0;       // since creation: rollout launches, those that carried a
     long long n_riding_launches = 0;        // combine, and combines launched on their own
@@ -445,7 +446,16 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.pk_nlast = e->T - (e->NGT - 1) * e->SG;
     a.Nrow = e->NBT * 4;
     a.pk_has_cg = 0;
-    a.store_e = (e->store_noise || e->strict) ? 1 : 0;   // (the strict kernel re-reads its noise)
+    // 0: the sampled noise is not materialised; 1: write-through stores; 2: non-temporal stores.
+    // A launch whose noise fits the 256 MB memory-side cache (C3: 240 MB, rewritten by every solve)
+    // is best served by write-through; beyond it the stores stream to HBM, and as write-through
+    // they hold the launch at ~3.1 TB/s (K = 1e6: 767 us) where non-temporal ones let it run at its
+    // VALU rate (640 us; 15-18 % from K = 2e5 up, equal at 300 MB, 2 % worse at 240 MB).
+    {
+        const double noise_bytes = 4.0 * (double)e->K * e->T * e->A;
+        a.store_e = (e->store_noise || e->strict) ? (noise_bytes > 320.0 * 1048576.0 ? 2 : 1) : 0;
+        if (e->tune_store_mode > 0 && a.store_e) a.store_e = e->tune_store_mode;
+    }
     for (int i = 0; i < e->A; ++i) {
         // scaled state of the packed kernel: d_p = sp (p - g_p), d_v = sv (v - g_v); a zero weight
         // gets the scale 2^-60, whose square vanishes against any cost (and is exact to undo)
@@ -821,6 +831,7 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     if (const char* env = getenv("MPPI_COMBINE_SPLITS")) e->tune_combine_splits = atoi(env);
     if (const char* env = getenv("MPPI_RIDE_MAX_TILES")) e->tune_ride_max_tiles = atoi(env);
     if (const char* env = getenv("MPPI_RIDE_LONG")) e->tune_ride_long = atoi(env);
+    if (const char* env = getenv("MPPI_STORE_MODE")) e->tune_store_mode = atoi(env);
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
     e->SG = mppi::rollout_group_steps(A);
     e->BPG = mppi::rollout_group_blocks(A);

@@ -131,7 +131,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
     P.dt2 = P.dt * P.dt;
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
-    const bool store_e = g.store_e != 0;     // wave-uniform: noise materialised in HBM or not
+    const int store_e = g.store_e;           // wave-uniform: 0 not materialised, 1 write-through, 2 non-temporal
     float* const cost_out = g.cost;
 
     // chunk geometry of this lane (same for every tile group)
@@ -205,8 +205,11 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                             typedef unsigned int v4u __attribute__((ext_vector_type(4)));
                             const v4u val = {__float_as_uint(eq[0]), __float_as_uint(eq[1]),
                                              __float_as_uint(eq[2]), __float_as_uint(eq[3])};
-                            __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
-                                                                   17 /* sc0 | sc1 */);
+                            if (store_e == 2)       // footprint beyond the memory-side cache: non-temporal
+                                __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024, 2);
+                            else
+                                __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                                       17 /* sc0 | sc1 */);
                         }
                     } else {
                         const float4 t = *reinterpret_cast<const float4*>(etile + (size_t)q * 256);

@@ -49,6 +49,9 @@
 #ifndef MPPI_PK_PRIO
 #define MPPI_PK_PRIO 2         // s_setprio of the latency-bound passes (the Philox pass runs at 0)
 #endif
+#ifndef MPPI_PK_STORE_AUX
+#define MPPI_PK_STORE_AUX 17   // cache policy of the noise stores: 17 = sc0 | sc1 (write-through)
+#endif
 #ifndef MPPI_PK_SCAN_BRANCH
 #define MPPI_PK_SCAN_BRANCH 0  // experiment: the absorb test of the segmented scans as an exec-masked branch
 #endif
@@ -140,7 +143,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
-    const bool store_e = g.store_e != 0;     // wave-uniform: noise materialised in HBM or not
+    const int store_e = g.store_e;           // wave-uniform: 0 noise not materialised, 1 write-through
+                                             // stores, 2 non-temporal stores (see engine.hip)
     float* const cost_out = g.cost;
 
     // ---- where this lane's group slots sit (the same for every tile) ---------------------------
@@ -256,8 +260,10 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, NQ * 1024, 0x00020000);
         }
 
-        // ---- pass 1a: draw (or load) the lane's noise and store it (write-through, see the
-        //      fused kernel) -------------------------------------------------------------------
+        // ---- pass 1a: draw (or load) the lane's noise and store it: write-through (sc0 sc1, see
+        //      the fused kernel) while the noise of a launch fits the 256 MB memory-side cache,
+        //      NON-TEMPORAL beyond (K = 2e5 ... 1e6 at 3-D: 15-18 % of the launch; at 240 MB
+        //      write-through is 2 % better; the engine chooses, RolloutArgs::store_e) --------------
         // Instruction priority by phase: the Philox pass can issue every cycle it is offered, the
         // passes after it are chains of dependent instructions.  Left at equal priority the OLDER
         // of the two waves of a SIMD wins every arbitration: the first block of a CU ran its tiles
@@ -300,14 +306,25 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 //  groups of the lane and runs out of registers; the VALU is saturated by one)
                 __builtin_amdgcn_sched_barrier(0);
                 if (store_e && (hd ? valid_h : valid_t)) {   // idle slots, samples >= K: no store
+                    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                    if (store_e == 2) {          // (the cache policy is an instruction modifier)
 #pragma unroll
-                    for (int b = 0; b < BPG; ++b) {
-                        const int q = gi * BPG + b;
-                        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-                        const v4u val = {__float_as_uint(e[q * 4]), __float_as_uint(e[q * 4 + 1]),
-                                         __float_as_uint(e[q * 4 + 2]), __float_as_uint(e[q * 4 + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
-                                                               17 /* sc0 | sc1 */);
+                        for (int b = 0; b < BPG; ++b) {
+                            const int q = gi * BPG + b;
+                            const v4u val = {__float_as_uint(e[q * 4]), __float_as_uint(e[q * 4 + 1]),
+                                             __float_as_uint(e[q * 4 + 2]), __float_as_uint(e[q * 4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                                   2 /* nt */);
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < BPG; ++b) {
+                            const int q = gi * BPG + b;
+                            const v4u val = {__float_as_uint(e[q * 4]), __float_as_uint(e[q * 4 + 1]),
+                                             __float_as_uint(e[q * 4 + 2]), __float_as_uint(e[q * 4 + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(val, e_rsrc, lane * 16, q * 1024,
+                                                                   MPPI_PK_STORE_AUX);
+                        }
                     }
                 }
             } else {
