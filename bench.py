@@ -718,8 +718,11 @@ def main():
         eng = sharded or m
         n_lat = 300 if K <= 200_000 else 50
         x_now = c["x0"].copy()
-        for _ in range(20):
+        t_r = time.perf_counter()          # (the legs before this one left the device idle: ramp)
+        n_r = 0
+        while n_r < 20 or (time.perf_counter() - t_r < 0.03 and n_r < 5000):
             eng.get_act()
+            n_r += 1
         fence()
         per_call = []
         tl = time.perf_counter()

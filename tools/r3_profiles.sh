@@ -23,6 +23,11 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3/bench_c2_driverli
 python bench.py --workload c3 > gpurun_out/r3/bench_c3.json 2> gpurun_out/r3/bench_c3.err
 python bench.py --workload c4 --no-cpu-baseline > gpurun_out/r3/bench_c4shard.json 2>/dev/null
 python bench.py --workload c4full --no-cpu-baseline --steps 300 --warmup 30 > gpurun_out/r3/bench_c4full.json 2>/dev/null
+python bench.py --workload c3x2 --no-cpu-baseline --steps 1000 > gpurun_out/r3/bench_c3x2.json 2>/dev/null
+{ for w in c2 c3 c4 c3x2 c3x4 c4full; do for m in 1 2 0; do MPPI_STORE_MODE=$m python bench.py --workload $w --steps $( [ $w = c4full ] && echo 200 || echo 1000 ) --warmup 20 --no-cpu-baseline --no-pmc --no-extra 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(\"$w MPPI_STORE_MODE=$m (1 write-through, 2 non-temporal, 0 the engine's choice by footprint): %.2f us per solve, kernel %.2f us\" % (d[\"ms_per_step\"]*1e3, d[\"roofline\"][\"kernel_ms\"]*1e3))"; done; done; } > gpurun_out/r3/store_mode.txt 2>&1
 python bench.py --workload c1 --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c1.json 2>/dev/null
 python bench.py --force-sharded --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c2_sharded_1rank.json 2>gpurun_out/r3/bench_fs.err
 for cfg in "2 10000 200 2000" "3 100000 200 500" "1 100 50 2000"; do timeout -k 10 120 tools/latency_probe $cfg; done > gpurun_out/r3/latency_probe.txt
