@@ -720,7 +720,8 @@ def main():
         x_now = c["x0"].copy()
         t_r = time.perf_counter()          # (the legs before this one left the device idle: ramp)
         n_r = 0
-        while n_r < 20 or (time.perf_counter() - t_r < 0.03 and n_r < 5000):
+        # (ranks of a sharded solve must make the same calls: a fixed count there)
+        while n_r < 20 or (dist is None and time.perf_counter() - t_r < 0.03 and n_r < 5000):
             eng.get_act()
             n_r += 1
         fence()
