@@ -86,6 +86,10 @@ struct RolloutArgs {
     int store_e;           // 0: the sampled noise is not written to Eint (mppi_set_noise_store);
                            // it is a pure function of (seed, solve, sample, step) and is
                            // regenerated on request (launch_regen_noise)
+    long long nt_from_tile;// packed kernel, store_e == 2: wavefront tiles below this index keep the
+                           // write-through store (the head of the buffer stays resident in the
+                           // memory-side cache and is overwritten there by the next solve), the rest
+                           // stream past it as non-temporal stores; 0 = all non-temporal
     float x0[8];           // host copy of the current state (travels by value in RolloutHot)
     // read only on the riding path (DeferredCombine), kept here so that they cost no kernel
     // argument registers: the tagged finished controls and the device watchdog words

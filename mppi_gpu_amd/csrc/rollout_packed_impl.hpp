@@ -143,6 +143,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
+    const long long nt_from_tile = g.nt_from_tile;
     const int store_e = g.store_e;           // wave-uniform: 0 noise not materialised, 1 write-through
                                              // stores, 2 non-temporal stores (see engine.hip)
     float* const cost_out = g.cost;
@@ -307,7 +308,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 __builtin_amdgcn_sched_barrier(0);
                 if (store_e && (hd ? valid_h : valid_t)) {   // idle slots, samples >= K: no store
                     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-                    if (store_e == 2) {          // (the cache policy is an instruction modifier)
+                    if (store_e == 2 && tile >= nt_from_tile) {   // (the cache policy is an instruction modifier)
 #pragma unroll
                         for (int b = 0; b < BPG; ++b) {
                             const int q = gi * BPG + b;
