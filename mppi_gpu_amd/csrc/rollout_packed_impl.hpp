@@ -52,6 +52,9 @@
 #ifndef MPPI_PK_STORE_AUX
 #define MPPI_PK_STORE_AUX 17   // cache policy of the noise stores: 17 = sc0 | sc1 (write-through)
 #endif
+#ifndef MPPI_PK_FIRST_STAGGER
+#define MPPI_PK_FIRST_STAGGER 2    // the first half of the grid runs its FIRST tile one priority level up
+#endif
 #ifndef MPPI_PK_SCAN_BRANCH
 #define MPPI_PK_SCAN_BRANCH 0  // experiment: the absorb test of the segmented scans as an exec-masked branch
 #endif
@@ -277,7 +280,17 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         if (my_turn) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
 #elif MPPI_PK_PRIO
+#if MPPI_PK_FIRST_STAGGER
+        // On the FIRST tile the first half of the grid -- the first block of every CU -- runs one
+        // priority level above the second half (noise pass 1 against 0, the passes after it 3
+        // against 2): the two blocks of a CU leave the Philox pass one after the other instead of
+        // together, and are out of phase -- one in its dependent passes while the other draws noise
+        // -- from the first tile on instead of drifting there (C3 66.5 -> 65.6 us per solve)
+        if (FIRST && bid < (nblk >> 1)) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#else
         __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
         float e[NE];
 #pragma unroll
@@ -342,7 +355,12 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
         if (my_turn) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(2);
 #elif MPPI_PK_PRIO
+#if MPPI_PK_FIRST_STAGGER >= 2
+        if (FIRST && bid < (nblk >> 1)) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
+#else
         __builtin_amdgcn_s_setprio(MPPI_PK_PRIO);
+#endif
 #endif
 
         // ---- pass 1b + scan: the scaled state every lane starts from.  Zero-state response of the
