@@ -453,10 +453,11 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     // A launch whose noise fits the 256 MB memory-side cache (C3: 240 MB, rewritten by every solve)
     // is best served by write-through; beyond it the stores stream to HBM, and as write-through
     // they hold the launch at ~3.1 TB/s (K = 1e6: 767 us) where non-temporal ones let it run at its
-    // VALU rate (640 us; 15-18 % from K = 2e5 up, equal at 300 MB, 2 % worse at 240 MB).
+    // VALU rate (640 us; 15-18 % from K = 2e5 up, equal or 3 % better at the C4 shard's 300 MB, 2 %
+    // worse at C3's 240 MB): non-temporal from the cache's own size up.
     {
         const double noise_bytes = 4.0 * (double)e->K * e->T * e->A;
-        a.store_e = (e->store_noise || e->strict) ? (noise_bytes > 320.0 * 1048576.0 ? 2 : 1) : 0;
+        a.store_e = (e->store_noise || e->strict) ? (noise_bytes > 256.0 * 1048576.0 ? 2 : 1) : 0;
         if (e->tune_store_mode > 0 && a.store_e) a.store_e = e->tune_store_mode;
         // bytes of noise one wavefront tile stores: nq float4 per lane
         const double tile_bytes = 1024.0 * (double)(e->nq > 0 ? e->nq : 1);
