@@ -747,6 +747,29 @@ def main():
                 step_b()
             m.sync_act()
             per_batch.append((time.perf_counter() - t1) / 20)
+        # the closed loop with a plant in it (reference src/main.cu:326-374: get_act -> simulate ->
+        # set_x): the host is away for 20 us between two calls; the time of the calls alone, with
+        # the next solve's noise drawn behind the combine meanwhile (mppi_set_noise_prefetch, the
+        # default) and without
+        plant = None
+        if sharded is None and hasattr(m, "set_noise_prefetch"):
+            plant = {"plant_step_us": 20.0}
+            for name, mode in (("prefetch_off_ms", 0), ("prefetch_auto_ms", 1)):
+                m.set_noise_prefetch(mode)
+                acc = 0.0
+                for i in range(n_lat + 20):
+                    t1 = time.perf_counter()
+                    m.get_act()
+                    t2 = time.perf_counter()
+                    if i >= 20:
+                        acc += t2 - t1
+                    m.set_x(x_now)
+                    while time.perf_counter() - t2 < 20e-6:
+                        pass
+                plant[name] = round(acc / n_lat * 1e3, 5)
+            plant["prefetch_counts"] = m.prefetch_counts()
+            plant["what"] = ("get_act alone, the host busy for plant_step_us between two calls; "
+                             "tools/latency_probe measures the same through the C ABI without Python")
         if dist is not None:
             tt = torch.tensor([t_get, t_loop], device="cpu" if args.rehearse_one_gpu else "cuda",
                               dtype=torch.float64)
@@ -763,6 +786,8 @@ def main():
                        what="100 batches of 20 solve_async + one wait, per-solve time of each batch"),
                    "what": "PointMassModel.get_act() through the Python binding: launch, solve, "
                            "wait for the action in host memory (reference src/main.cu:329-332)"}
+        if plant is not None:
+            latency["closed_loop_with_plant_step"] = plant
 
     # effective sample size of the benchmark's last solve (lambda = 1, the reference's value): says
     # in which regime the exp-weighted update ran

@@ -186,6 +186,15 @@ class PointMassModel:
         """0 deferred combine (default), 1 eager; see the header."""
         check(self._lib.mppi_set_pipeline(self._h, int(mode)))
 
+    def set_noise_prefetch(self, mode):
+        """0 never, 1 auto (default), 2 whenever possible; see the header."""
+        check(self._lib.mppi_set_noise_prefetch(self._h, int(mode)))
+
+    def prefetch_counts(self):
+        out = (C.c_longlong * 2)()
+        check(self._lib.mppi_get_prefetch_counts(self._h, out))
+        return {"launched": int(out[0]), "used": int(out[1])}
+
     def pipeline(self):
         """{"mode": 0 | 1, "degraded": the engine chose mode 1 itself after a watchdog trip}"""
         mode, deg = C.c_int(), C.c_int()

@@ -34,6 +34,8 @@ SIGNATURES = {
     "mppi_set_params": (C.c_int, [engine_p, C.c_float, c_float_p, c_float_p]),
     "mppi_set_seed": (C.c_int, [engine_p, C.c_ulonglong]),
     "mppi_set_noise": (C.c_int, [engine_p, c_float_p]),
+    "mppi_set_noise_prefetch": (C.c_int, [engine_p, C.c_int]),
+    "mppi_get_prefetch_counts": (C.c_int, [engine_p, C.POINTER(C.c_longlong)]),
     "mppi_set_ref_compat": (C.c_int, [engine_p, C.c_int]),
     "mppi_set_noise_store": (C.c_int, [engine_p, C.c_int]),
     "mppi_set_action_limit": (C.c_int, [engine_p, c_float_p]),

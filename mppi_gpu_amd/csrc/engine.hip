@@ -146,6 +146,23 @@ struct mppi_engine {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the most recent enqueue
 
+    // noise prefetch (mppi_set_noise_prefetch): while the host holds the action of solve j, extra
+    // blocks of that solve's stand-alone combine launch draw the noise of solve j+1 into a second
+    // buffer in the rollout's own tile layout; the next rollout then LOADS it (its injected-noise
+    // instantiation: 6.8 instead of 10.2 us at C2) and computes the same bits
+    int pf_mode = 1;                     // 0 off, 1 auto, 2 whenever possible
+    float* d_Epf = nullptr;
+    size_t epf_floats = 0;
+    bool pf_valid = false;
+    unsigned long long pf_idx = 0, pf_seed = 0;
+    float pf_sigma[4] = {0.f, 0.f, 0.f, 0.f};
+    mppi::ELayout pf_lay = {0, 1, 0, 0, 0, 0};
+    hipStream_t pf_on_stream = nullptr;  // the stream whose combine launch carried the prefetch
+    long long n_pf_launched = 0, n_pf_used = 0;
+    std::chrono::steady_clock::time_point t_return;   // when the last blocking get_act returned
+    bool t_return_valid = false;
+    double think_ema_us = 0.0;           // host time between a get_act's return and the next call
+
     // direct peer exchange (mppi_xchg_*)
     int xg_rank = -1, xg_world = 0, xg_W = 0;
     bool xg_connected = false;
@@ -351,6 +368,8 @@ int ensure_geometry(mppi_engine_t* e)
                     C);
 
     const size_t need = (size_t)ntb * 4 * nq * 64 * 4;      // 4 wavefront tiles per tile group
+    e->pf_valid = false;                                   // (another layout: a prefetch is stale)
+    if (e->pf_on_stream) HIPCHK(hipStreamSynchronize(e->pf_on_stream));
     if (need > e->eint_floats) {
         if (e->d_Eint) HIPCHK(hipFree(e->d_Eint));
         e->d_Eint = nullptr;
@@ -708,6 +727,17 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
         e->inj_dirty = false;
     }
     float* Ecur = e->d_Eint;
+    // a valid prefetch of THIS solve's noise (same stream of counters, same layout): load it
+    bool use_pf = e->pf_valid && !e->injected && !e->strict && e->d_Epf && e->pf_idx == e->solve_idx &&
+                  e->pf_seed == e->seed && memcmp(&e->pf_lay, &lay, sizeof lay) == 0 &&
+                  e->epf_floats == e->eint_floats;
+    for (int i = 0; i < e->A; ++i) use_pf = use_pf && e->pf_sigma[i] == e->sigma[i];
+    e->pf_valid = false;
+    if (use_pf) {
+        // (the prefetch ran on the stream of the last blocking call: the same one, normally)
+        if (e->pf_on_stream && e->pf_on_stream != st) HIPCHK(hipStreamSynchronize(e->pf_on_stream));
+        Ecur = e->d_Epf;
+    }
 
     mppi::RolloutArgs ra;
     memset(&ra, 0, sizeof ra);
@@ -745,17 +775,23 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     if ((rc = prof_pair(e, tm, 0))) return rc;
     if (tm.start) e->ev_clean.push_back(e->prof_prev ? 1 : 0);
     e->prof_prev = tm.start != nullptr;
-    const bool sample_in_kernel = !e->injected;
+    const bool sample_in_kernel = !e->injected && !use_pf;
     if (e->strict)
         HIPCHK(mppi::launch_rollout_stream(e->A, sample_in_kernel, e->grid, ra, st, tm));
     else if (e->packed)
         HIPCHK(mppi::launch_rollout_packed(e->A, e->ng, sample_in_kernel, e->grid, ra, dc, st, tm));
     else
         HIPCHK(mppi::launch_rollout_fused(e->A, e->NGt, sample_in_kernel, e->grid, ra, dc, st, tm));
+    if (use_pf) {           // the buffers change roles: what this solve used is now "the" noise
+        float* t = e->d_Eint;
+        e->d_Eint = e->d_Epf;
+        e->d_Epf = t;
+        e->n_pf_used += 1;
+    }
     e->last_E = Ecur;
     e->last_lay = lay;
     e->last_idx = e->solve_idx;
-    e->last_stored = e->injected || e->store_noise || e->strict;
+    e->last_stored = e->injected || e->store_noise || e->strict || use_pf;
     e->last_seed = e->seed;
     for (int i = 0; i < 4; ++i) e->last_sigma[i] = e->sigma[i];
     memcpy(e->x0_last, e->x0, sizeof e->x0);
@@ -811,6 +847,70 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
     return MPPI_OK;
 }
 
+// Should the combine launch of the blocking call that is about to wait also draw the NEXT solve's
+// noise?  Auto mode: always for launches of one tile per block -- a latency chain that leaves the
+// chip mostly idle -- and for longer (VALU-bound) launches only when the host's think time between
+// two calls has been long enough to hide it.
+bool want_prefetch(const mppi_engine_t* e)
+{
+    if (e->pf_mode == 0 || e->injected || e->strict || !e->store_noise || !e->geom_ok || !e->data_set)
+        return false;
+    if (e->fault || !e->pending || e->pending_mode == 0) return false;
+    if (4.0 * (double)e->eint_floats > 1.5e9) return false;     // (a second buffer of that size: no)
+    if (e->pf_mode == 1) {
+        // the Philox + Box-Muller pass alone: 173 ns per wave-block and SIMD.  The
+        // next rollout is stream-ordered behind these blocks: they pay when they are over before
+        // it arrives (the host's think time + its 2.7 us of enqueue), or when they are short
+        const double pf_us = (double)e->K * e->NBT / 64.0 * 0.173 / 1024.0;
+        const bool chain = e->grid == e->n_tileblk;      // one tile per block: a latency chain
+        if (chain ? (pf_us > 1.0 && e->think_ema_us < pf_us)
+                  : (e->think_ema_us < 1.5 * pf_us + 20.0))
+            return false;
+    }
+    return true;
+}
+
+// launch the pending combine on its own, with the next solve's noise drawn behind it
+int flush_pending_with_prefetch(mppi_engine_t* e)
+{
+    if (!e->pending) return MPPI_OK;
+    if (!want_prefetch(e)) return flush_pending(e);
+    const hipStream_t st = e->pending_stream;
+    if (e->epf_floats != e->eint_floats) {
+        if (e->pf_on_stream) HIPCHK(hipStreamSynchronize(e->pf_on_stream));
+        if (e->d_Epf) HIPCHK(hipFree(e->d_Epf));
+        e->d_Epf = nullptr;
+        e->epf_floats = 0;
+        HIPCHK(hipMalloc(&e->d_Epf, e->eint_floats * sizeof(float)));
+        HIPCHK(hipMemsetAsync(e->d_Epf, 0, e->eint_floats * sizeof(float), st));
+        e->epf_floats = e->eint_floats;
+    }
+    mppi::CombineArgs ca;
+    e->u_epoch += 1;
+    if (e->u_epoch == 0) e->u_epoch = 1;
+    fill_own_combine(e, ca, e->pending_idx, e->u_epoch, e->pending_mode, e->pending_xseq);
+    mppi::LaunchTiming tm;
+    int rc = prof_pair(e, tm, 1);
+    if (rc) return rc;
+    e->pending = false;
+#ifdef MPPI_TRACE
+    ca.trace = nullptr;
+#endif
+    const mppi::ELayout lay = {e->packed ? 1 : 0, e->C, e->nq, e->ng, e->NGT, e->TPW};
+    HIPCHK(mppi::launch_combine_small_prefetch(e->A, ca, e->d_Epf, lay, e->K, e->T,
+                                               (long long)e->n_tileblk * 4, e->seed, e->solve_idx,
+                                               e->k_offset, e->sigma, st, tm));
+    e->n_combine_launches += 1;
+    e->pf_valid = true;
+    e->pf_idx = e->solve_idx;
+    e->pf_seed = e->seed;
+    e->pf_lay = lay;
+    e->pf_on_stream = st;
+    for (int i = 0; i < 4; ++i) e->pf_sigma[i] = e->sigma[i];
+    e->n_pf_launched += 1;
+    return MPPI_OK;
+}
+
 int create_common(int K, long long k_offset, bool sharded, int T, float dt, int S, int A,
                   int verbose, mppi_engine** out)
 {
@@ -839,6 +939,7 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     if (const char* env = getenv("MPPI_RIDE_MAX_TILES")) e->tune_ride_max_tiles = atoi(env);
     if (const char* env = getenv("MPPI_RIDE_LONG")) e->tune_ride_long = atoi(env);
     if (const char* env = getenv("MPPI_STORE_MODE")) e->tune_store_mode = atoi(env);
+    if (const char* env = getenv("MPPI_PREFETCH")) e->pf_mode = atoi(env);
     if (const char* env = getenv("MPPI_NT_RESIDENT_MB")) e->tune_nt_resident_mb = atoi(env);
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
     e->SG = mppi::rollout_group_steps(A);
@@ -948,6 +1049,8 @@ void mppi_destroy(mppi_engine* e)
     (void)hipFree(e->d_args);
     (void)hipFree(e->d_slab);
     (void)hipFree(e->d_tickets);
+    if (e->pf_on_stream) (void)hipStreamSynchronize(e->pf_on_stream);
+    (void)hipFree(e->d_Epf);
     (void)hipFree(e->d_Einj);
     (void)hipFree(e->d_scratch);
     if (e->h_act) (void)hipHostFree(e->h_act);
@@ -1002,6 +1105,12 @@ int mppi_solve_async(mppi_engine* e, void* stream)
 {
     if (!e) return fail(MPPI_EINVAL, "null engine");
     if (e->fault || (e->h_err && *e->h_err)) return check_watchdog(e);   // sticky until set_data
+    if (e->t_return_valid) {     // the host's think time since the last blocking call returned
+        const double gap = std::chrono::duration<double, std::micro>(
+                               std::chrono::steady_clock::now() - e->t_return).count();
+        e->think_ema_us = e->think_ema_us > 0.0 ? 0.5 * e->think_ema_us + 0.5 * gap : gap;
+        e->t_return_valid = false;
+    }
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const bool defer = e->defer != 0;
     int rc = enqueue_rollout(e, st, defer);
@@ -1055,7 +1164,8 @@ int mppi_wait_act(mppi_engine* e, float* next_act)
 {
     if (!e || !next_act) return fail(MPPI_EINVAL, "null argument");
     int rc;
-    if ((rc = flush_pending(e))) return rc;
+    // (with the next solve's noise drawn behind the combine, while the host waits / thinks)
+    if ((rc = flush_pending_with_prefetch(e))) return rc;
     // The closed-loop call: poll the pinned words the combine kernel writes the action into
     // (8-byte {value, tag} stores) instead of sleeping in hipStreamSynchronize, whose wake-up
     // costs more than the solve at K = 1e4; after 300 us of polling fall back to the blocking
@@ -1076,6 +1186,8 @@ int mppi_wait_act(mppi_engine* e, float* next_act)
     }
     if ((rc = check_watchdog(e))) return rc;
     read_action(e, next_act);
+    e->t_return = std::chrono::steady_clock::now();
+    e->t_return_valid = true;
     return MPPI_OK;
 }
 
@@ -1324,6 +1436,23 @@ int mppi_set_pipeline(mppi_engine* e, int on)
     if (on < 0 || on > 1) return fail(MPPI_EINVAL, "pipeline mode must be 0 or 1");
     e->defer = on == 0 ? 1 : 0;
     e->degraded = false;        // an explicit choice overrides the watchdog's
+    return MPPI_OK;
+}
+
+int mppi_set_noise_prefetch(mppi_engine* e, int mode)
+{
+    if (!e) return fail(MPPI_EINVAL, "null engine");
+    if (mode < 0 || mode > 2) return fail(MPPI_EINVAL, "prefetch mode must be 0, 1 or 2");
+    e->pf_mode = mode;
+    if (mode == 0) e->pf_valid = false;
+    return MPPI_OK;
+}
+
+int mppi_get_prefetch_counts(mppi_engine* e, long long out[2])
+{
+    if (!e || !out) return fail(MPPI_EINVAL, "null argument");
+    out[0] = e->n_pf_launched;
+    out[1] = e->n_pf_used;
     return MPPI_OK;
 }
 

@@ -296,6 +296,80 @@ __global__ void k_regen_noise(float* E, int K, int TA, int NBT, unsigned long lo
     }
 }
 
+// The noise of solve `solve_idx` written AHEAD of its rollout, in the rollout's own tile layout (one
+// thread per float4 slot: a wavefront stores 1 KiB contiguous, like pass 1a), by the device
+// functions the rollout draws with: the rollout then LOADS it (its injected-noise instantiation)
+// and computes the very bits it would have drawn.  It runs as EXTRA BLOCKS of the stand-alone
+// combine launch of a blocking call (k_combine_small_prefetch): the combine blocks come first and
+// at high priority -- the host polls the action words they write, not the end of the launch -- and
+// the prefetch blocks fill the chip behind them while the host holds the action; the next rollout
+// follows on the same stream, so no event and no second queue is involved.
+struct PrefetchArgs {
+    float* Eint;
+    ELayout L;
+    int K, TA, NBT;
+    unsigned long long seed, blk_base;
+    long long k_offset;
+    float sig[4];
+    long long n_slots;
+};
+
+template <int A>
+__device__ __forceinline__ void prefetch_body(const PrefetchArgs& p, long long first, long long stride)
+{
+    constexpr int BPG = Dim<A>::BPG;
+    for (long long g = first; g < p.n_slots; g += stride) {
+        const int lane = (int)(g & 63);
+        const long long tq = g >> 6;
+        const int q = (int)(tq % p.L.nq);
+        const long long tile = tq / p.L.nq;
+        long long k;
+        int b;
+        bool valid;
+        if (p.L.packed) {
+            const int s = lane * p.L.NG + q / BPG;            // group slot of the wavefront
+            const int j = s / p.L.NGT;
+            k = tile * p.L.TPW + j;
+            b = (s - j * p.L.NGT) * BPG + q % BPG;
+            valid = j < p.L.TPW && k < p.K && b < p.NBT;
+        } else {
+            const int c = lane & (p.L.C - 1);
+            k = tile * (64 / p.L.C) + lane / p.L.C;
+            b = c * p.L.nq + q;
+            valid = k < p.K && b < p.NBT;
+        }
+        if (!valid) continue;
+        const uint4 r = PhiloxAt::block(p.blk_base + (unsigned long long)b,
+                                        (unsigned long long)(p.k_offset + k), p.seed);
+        float z[4], e[4];
+        box_muller_hw(r.x, r.y, z[0], z[1]);
+        box_muller_hw(r.z, r.w, z[2], z[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = b * 4 + i;
+            e[i] = (n < p.TA) ? p.sig[n % A] * z[i] : 0.0f;    // (a ragged horizon: zero past T)
+        }
+        *reinterpret_cast<float4*>(p.Eint + g * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+template <int A>
+__global__ void __launch_bounds__(kRolloutThreads)
+k_combine_small_prefetch(const CombineArgs a, const PrefetchArgs p, const int n_comb)
+{
+    if ((int)blockIdx.x < n_comb) {
+        __builtin_amdgcn_s_setprio(3);
+        __shared__ float smem[combine_smem_floats<kRolloutThreads>()];
+        combine_body<kRolloutThreads, kSmallCombineNR>(a, (int)blockIdx.x,
+                                                       carve_combine_smem<kRolloutThreads>(smem));
+        return;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    const long long nb = (long long)gridDim.x - n_comb;
+    prefetch_body<A>(p, ((long long)blockIdx.x - n_comb) * kRolloutThreads + threadIdx.x,
+                     nb * kRolloutThreads);
+}
+
 // weights_kernel, reference src/point_mass.cu:743-754 (double intermediates kept).
 __global__ void k_weights(const float* cost, const DevState* dev, float lambda, float* wts,
                           int K)
@@ -591,6 +665,36 @@ hipError_t launch_regen_noise(int A, float* E, int K, int T, unsigned long long 
         case 2: hipLaunchKernelGGL(k_regen_noise<2>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
         case 3: hipLaunchKernelGGL(k_regen_noise<3>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
         case 4: hipLaunchKernelGGL(k_regen_noise<4>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_small_prefetch(int A, const CombineArgs& a, float* Eint, const ELayout& lay,
+                                         int K, int T, long long n_tiles, unsigned long long seed,
+                                         unsigned long long solve_idx, long long k_offset,
+                                         const float* sg, hipStream_t st, LaunchTiming tm)
+{
+    PrefetchArgs p;
+    p.Eint = Eint;
+    p.L = lay;
+    p.K = K;
+    p.TA = T * A;
+    p.NBT = (p.TA + 3) / 4;
+    p.seed = seed;
+    p.blk_base = solve_idx * (unsigned long long)p.NBT;
+    p.k_offset = k_offset;
+    for (int i = 0; i < 4; ++i) p.sig[i] = sg[i];
+    p.n_slots = n_tiles * lay.nq * 64;
+    const int n_comb = a.n_cols * a.RS;
+    long long nb = (p.n_slots + kRolloutThreads - 1) / kRolloutThreads;
+    if (nb > 4096) nb = 4096;
+    const dim3 grid((unsigned)(n_comb + nb)), block(kRolloutThreads);
+    switch (A) {
+        case 1: MPPI_LAUNCH(k_combine_small_prefetch<1>, grid, block, 0, st, tm, a, p, n_comb); break;
+        case 2: MPPI_LAUNCH(k_combine_small_prefetch<2>, grid, block, 0, st, tm, a, p, n_comb); break;
+        case 3: MPPI_LAUNCH(k_combine_small_prefetch<3>, grid, block, 0, st, tm, a, p, n_comb); break;
+        case 4: MPPI_LAUNCH(k_combine_small_prefetch<4>, grid, block, 0, st, tm, a, p, n_comb); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -340,6 +340,15 @@ hipError_t launch_regen_noise(int A, float* E_ktA, int K, int T, unsigned long l
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 constexpr size_t kDefaultLdsBytes = 64 * 1024;
 
+// The stand-alone 256-thread combine (prepared like launch_combine_small) with the noise of solve
+// `solve_idx` drawn by extra blocks behind it, in the tile layout `lay` (n_tiles wavefront tiles):
+// bit for bit what the sampling rollout would draw and store
+hipError_t launch_combine_small_prefetch(int A, const CombineArgs& a_prepared, float* Eint,
+                                         const ELayout& lay, int K, int T, long long n_tiles,
+                                         unsigned long long seed, unsigned long long solve_idx,
+                                         long long k_offset, const float* sigma4, hipStream_t st,
+                                         LaunchTiming tm = LaunchTiming());
+
 // launch with or without dispatch timing
 #define MPPI_LAUNCH(kernel, grid, block, lds, st, tm, ...)                                       \
     do {                                                                                         \

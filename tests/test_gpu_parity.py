@@ -686,6 +686,78 @@ def test_noise_mode_change_replans_the_riding_launch(gpu):
         assert cnt["riding"] == 4, cnt
 
 
+@pytest.mark.parametrize("A,K,T,packing", [(2, 10000, 200, 0), (3, 3000, 50, 0), (3, 3000, 50, 4),
+                                            (3, 30011, 200, 0), (1, 700, 33, 0)])
+def test_noise_prefetch_gives_the_bits_of_in_kernel_sampling(gpu, A, K, T, packing):
+    """mppi_set_noise_prefetch: the combine launch of a blocking get_act carries low-priority
+    blocks that draw the NEXT solve's noise; the next rollout loads it (injected-noise
+    instantiation) instead of drawing it.  Same counters, same device functions: the chain must end in the bits of the
+    chain that samples inside the rollout, with set_x / set_params / get_inf / solve_async in
+    between, and the noise get_inf hands out must be the stream's."""
+    c = ol.make_case(A, 1, T, seed=151, u_scale=0.03)
+    outs = {}
+    for mode in (0, 2):
+        with _model(gpu, A, K, T, c) as m:
+            if packing:
+                m.set_packing(packing)
+            m.set_noise_prefetch(mode)
+            m.set_seed(21)
+            m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+            log = []
+            for it in range(4):
+                log.append(m.get_act())
+            m.set_x((c["x0"] * 0.8).astype(np.float32))
+            log.append(m.get_act())
+            e_mid = m.get_inf(x=False, u=False, cost=False, beta=False, nabla=False, weight=False)["e"]
+            m.set_params(3.0)                     # lambda only: the prefetched noise stays valid
+            log.append(m.get_act())
+            m.solve_async(); m.solve_async()      # (the first of them may load a prefetch)
+            log.append(m.sync_act())
+            m.set_params(3.0, sigma=[0.05] * A)   # another sigma: a prefetch in flight is stale
+            log.append(m.get_act())
+            log.append(m.get_act())
+            inf = m.get_inf(x=False)
+            cnt = m.prefetch_counts()
+        outs[mode] = (log, e_mid, inf, cnt)
+    (l0, e0, i0, c0), (l2, e2, i2, c2) = outs[0], outs[2]
+    assert c0 == {"launched": 0, "used": 0}
+    assert c2["used"] >= 5 and c2["launched"] >= c2["used"], c2
+    for a, b in zip(l0, l2):
+        assert np.array_equal(a, b), "prefetched noise must give the bits of in-kernel sampling"
+    assert np.array_equal(e0, e2) and np.array_equal(i0["e"], i2["e"])
+    assert np.array_equal(i0["u"], i2["u"]) and np.array_equal(i0["cost"], i2["cost"])
+    h = ol.noise(21, 4, 0, min(K, 64), T, A, [SIGMA] * A)          # solve index 4 = the fifth solve
+    np.testing.assert_allclose(e2[:64], h, rtol=0, atol=SIGMA * 2e-5)
+
+
+def test_noise_prefetch_auto_mode_follows_the_launch_length_and_the_think_time(gpu):
+    """mode 1: a launch of one tile per block prefetches when the draw is short (< 1 us: the
+    shipped 3-D config) or over before the host is back; a long (VALU-bound) launch only when the
+    host's think time between two blocking calls hides the whole draw."""
+    import time
+    c = ol.make_case(3, 1, 50, seed=5, u_scale=0.0)
+    with _model(gpu, 3, 3000, 50, c) as m:               # the shipped config: a 0.3 us draw
+        for _ in range(6):
+            m.get_act()
+        assert m.prefetch_counts()["used"] >= 4
+    c = ol.make_case(2, 1, 200, seed=5, u_scale=0.0)
+    with _model(gpu, 2, 10000, 200, c) as m:             # C2: one tile per block, a 2.6 us draw
+        for _ in range(6):
+            m.get_act()
+            time.sleep(0.0005)
+        assert m.prefetch_counts()["used"] >= 3
+    c = ol.make_case(3, 1, 200, seed=5, u_scale=0.0)
+    with _model(gpu, 3, 60000, 200, c) as m:             # packed, 6 tiles per block
+        for _ in range(6):
+            m.get_act()                                  # back to back: no think time
+        assert m.prefetch_counts() == {"launched": 0, "used": 0}
+        for _ in range(6):
+            m.get_act()
+            time.sleep(0.003)                            # a 300 Hz loop
+        cnt = m.prefetch_counts()
+        assert cnt["used"] >= 3, cnt
+
+
 def test_deferred_combine_interleaved_with_everything_else(gpu):
     """A pending combine must be flushed by every call that reads or changes what it touches:
     set_x between asynchronous solves (rides on), get_u / get_inf / set_params / set_tuning /

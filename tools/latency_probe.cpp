@@ -4,7 +4,9 @@
 //   get_act + set_x              (the closed-loop pattern, src/main.cu:326-374)
 //   solve_async + sync_act       (same work, hipStreamSynchronize instead of polling)
 //   solve_async x N, one sync    (pipelined: what bench.py's headline times)
-// usage: latency_probe [A K T [n]]      build: g++ -O2 -std=c++17 -Iinclude tools/latency_probe.cpp
+//   get_act with the host busy for `think_us` between two calls (a plant step; the time of the
+//   calls alone) -- what the noise prefetch of mppi_set_noise_prefetch is for
+// usage: latency_probe [A K T [n [think_us]]]      build: g++ -O2 -std=c++17 -Iinclude tools/latency_probe.cpp
 //        -Lmppi_gpu_amd/lib -lmppi_gpu_amd -Wl,-rpath,$PWD/mppi_gpu_amd/lib -Wl,-rpath,/opt/rocm/lib
 #include "mppi_gpu_amd.h"
 
@@ -24,6 +26,7 @@ int main(int argc, char** argv)
 {
     const int A = argc > 3 ? atoi(argv[1]) : 2, K = argc > 3 ? atoi(argv[2]) : 10000,
               T = argc > 3 ? atoi(argv[3]) : 200, n = argc > 4 ? atoi(argv[4]) : 2000;
+    const double think_us = argc > 5 ? atof(argv[5]) : 0.0;
     const int S = 2 * A;
     const float goals[4][8] = {{1, 0}, {1, 0, 0, 0}, {1, .5f, .75f, 0, 0, 0}, {1, .5f, .75f, .25f}};
     const float ws[4][8] = {{1, 5}, {1, 1, 50, 50}, {1, 1, 1, 5, 5, 5}, {1, 1, 1, 1, 5, 5, 5, 5}};
@@ -41,6 +44,19 @@ int main(int argc, char** argv)
     for (int i = 0; i < n; ++i) { CK(mppi_get_act(e, act.data())); CK(mppi_set_x(e, x.data())); }
     const double t_loop = (now_us() - t0) / n;
 
+    double t_think = 0.0;        // the calls alone, with the host away for think_us in between
+    if (think_us > 0.0) {
+        for (int i = 0; i < n + 20; ++i) {
+            const double a = now_us();
+            CK(mppi_get_act(e, act.data()));
+            const double b = now_us();
+            if (i >= 20) t_think += b - a;
+            CK(mppi_set_x(e, x.data()));
+            while (now_us() - b < think_us) {}
+        }
+        t_think /= n;
+    }
+
     t0 = now_us();
     for (int i = 0; i < n; ++i) { CK(mppi_solve_async(e, nullptr)); CK(mppi_sync_act(e, act.data())); }
     const double t_sync = (now_us() - t0) / n;
@@ -53,8 +69,9 @@ int main(int argc, char** argv)
     const double t_pipe = (now_us() - t0) / n;
 
     printf("{\"A\": %d, \"K\": %d, \"T\": %d, \"n\": %d, \"get_act_us\": %.2f, \"get_act_set_x_us\": %.2f, "
-           "\"solve_async_sync_us\": %.2f, \"pipelined_us\": %.2f, \"enqueue_only_us\": %.2f}\n",
-           A, K, T, n, t_get, t_loop, t_sync, t_pipe, t_enq);
+           "\"solve_async_sync_us\": %.2f, \"pipelined_us\": %.2f, \"enqueue_only_us\": %.2f, "
+           "\"think_us\": %.1f, \"get_act_with_think_us\": %.2f}\n",
+           A, K, T, n, t_get, t_loop, t_sync, t_pipe, t_enq, think_us, t_think);
     mppi_destroy(e);
     return 0;
 }
