@@ -166,6 +166,7 @@ struct mppi_engine {
     // direct peer exchange (mppi_xchg_*)
     int xg_rank = -1, xg_world = 0, xg_W = 0;
     bool xg_connected = false;
+    int xg_ranks_on_my_device = 1;                     // ranks (this one included) whose inbox is on THIS GPU
     bool xg_peer_on_my_device = false;                 // a peer's inbox lives on THIS GPU (rehearsals,
                                                        // GPU sharing): see enqueue_rollout
     unsigned long long* xg_inbox = nullptr;            // this rank's inbox (uncached device memory)
@@ -697,7 +698,11 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
             probe.TA = e->TA;
             probe.n_parts = e->grid;
             probe.row_splits = e->tune_combine_splits;
-            co_resident = (long long)e->grid + mppi::combine_small_prepare(probe) <= e->resident_ride;
+            // (an exchange that rides waits for the peers' words: the launches of all the ranks
+            //  that share this GPU must then fit the chip TOGETHER)
+            const long long share = e->pending_mode == 2 ? e->xg_ranks_on_my_device : 1;
+            co_resident = share * ((long long)e->grid + mppi::combine_small_prepare(probe))
+                          <= e->resident_ride;
         }
         // The PACKED kernel runs its first tile as a copy of its own (rollout_packed_impl.hpp): what
         // riding adds -- polling for the controls -- is outside its steady-state loop, so a combine
@@ -1578,11 +1583,15 @@ int mppi_xchg_connect(mppi_engine* e, const void* handles, void* const* same_pro
         int my_dev = 0;
         (void)hipGetDevice(&my_dev);
         e->xg_peer_on_my_device = false;
+        e->xg_ranks_on_my_device = 1;
         for (int g = 0; g < e->xg_world; ++g) {
             if (g == e->xg_rank) continue;
             hipPointerAttribute_t at;
             if (hipPointerGetAttributes(&at, tab[g]) == hipSuccess) {
-                if (at.device == my_dev) e->xg_peer_on_my_device = true;
+                if (at.device == my_dev) {
+                    e->xg_peer_on_my_device = true;
+                    e->xg_ranks_on_my_device += 1;
+                }
             } else {
                 (void)hipGetLastError();
             }

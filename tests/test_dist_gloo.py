@@ -199,3 +199,16 @@ def test_direct_peer_exchange_equals_collective_bitwise(gpu, world, K, A, T):
     assert (tr_c, tr_d, tr_a) == ("collective", "direct", "direct")
     assert np.array_equal(acts_c, acts_d) and np.array_equal(U_c, U_d)
     assert np.array_equal(acts_c, acts_a) and np.array_equal(U_c, U_a)
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_gpu_do_not_wait_for_each_other_in_vain(gpu):
+    """Four processes on ONE GPU at the bench's shard size (625 blocks each): their riding launches
+    wait for each other's words, and all four do not fit the chip together -- the engine must see
+    the peers' inboxes on its own device and launch those combines on their own instead of
+    running into the exchange time-out."""
+    seed, world, K, A, T = 7, 4, 40000, 2, 200
+    acts_c, U_c, _ = _run_gpu_ranks(world, K, A, T, seed, "collective", 37700)
+    acts_d, U_d, tr = _run_gpu_ranks(world, K, A, T, seed, "direct", 39700)
+    assert tr == "direct"
+    assert np.array_equal(acts_c, acts_d) and np.array_equal(U_c, U_d)
