@@ -40,12 +40,18 @@ L = open(os.path.join(tmp, "unit.s")).read().splitlines()
 starts = [i for i, l in enumerate(L) if l.startswith(key) and l.rstrip().endswith(":") is False and ":" in l]
 for st in starts:
     name = L[st].split(":")[0]
-    if "Lb1E" not in name:          # the sampling instantiations
+    if kind == "packed":
+        if f"ILi{A}ELi4ELb1ELb0E" not in name and f"ILi{A}ELi" not in name:
+            continue
+        if not re.search(r"ELb1ELb[01]EE", name):   # SAMPLE = true; RAGGED printed with the name
+            continue
+    elif "Lb1E" not in name:        # the sampling instantiations
         continue
     en = next(i for i in range(st, len(L)) if L[i].startswith(".Lfunc_end"))
     body = L[st:en]
     marks = [(i, l.strip()) for i, l in enumerate(body) if "; MARK" in l]
     print(name, "lines", len(body))
+    by_op = collections.Counter()
     for (a, la), (b, lb) in zip(marks, marks[1:] + [(len(body), "END")]):
         c = collections.Counter()
         for l in body[a:b]:
@@ -59,4 +65,14 @@ for st in starts:
             elif k.startswith("ds_"): c["lds"] += 1
             elif k.startswith("s_"): c["salu"] += 1
             elif k.startswith(("buffer_", "global_")): c["vmem"] += 1
+            # a VALU instruction that READS an SGPR issues at half rate on gfx950 (4.2 against 2.4
+            # SIMD cycles, tools/ubench_int.hip; inline constants and literals do not): count them
+            if k.startswith("v_") and not k.startswith(("v_readlane", "v_readfirstlane", "v_mad_u64",
+                                                         "v_cmp", "v_writelane")):
+                ops = l.split(";")[0].strip().split(None, 1)
+                srcs = ops[1].split(",")[1:] if len(ops) > 1 else []
+                if any(re.match(r"\s*-?\|?s(\d+|\[)", o) for o in srcs):
+                    c["valu_sgpr_src"] += 1
+                    by_op[k] += 1
         print(f"  {la:12s} -> {lb:12s} {dict(c)}")
+    print("  VALU with an SGPR source, by opcode:", dict(by_op.most_common(12)))
