@@ -298,9 +298,11 @@ def rocprof_kernel_ms_live(workload, kernel_sub, extra_args=(), steps=2000):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-# issue cost of a wave64 instruction in SIMD cycles at the nominal 2.4 GHz, measured with
-# tools/ubench_issue on MI355X (profiles/r02_ubench_issue.txt)
-ISSUE_COST = {"INT64": 6.3, "TRANS_F32": 8.4, "BITOP3": 4.2, "OTHER": 2.3}
+# issue cost of a wave64 instruction in SIMD cycles at the nominal 2.4 GHz, measured on MI355X with
+# tools/ubench_issue (profiles/r02_ubench_issue.txt: transcendentals, plain fp32) and
+# tools/ubench_int (profiles/r03_ubench_int.txt: v_mad_u64_u32 alone 4.5-4.9 -- round 2's 6.3 had
+# the move that widens its addend in it --, v_bitop3_b32 with its SGPR key 4.25)
+ISSUE_COST = {"INT64": 4.7, "TRANS_F32": 8.4, "BITOP3": 4.25, "OTHER": 2.3}
 
 
 def pmc_alu_live(workload, kernel_sub, extra_args=(), kernel_ms=None):
@@ -335,7 +337,8 @@ def pmc_alu_live(workload, kernel_sub, extra_args=(), kernel_ms=None):
             "dispatches": n,
             "source": "measured in this run: three child passes of this command under rocprofv3 "
                       "--kernel-trace --pmc (SQ instruction counters; SQ_ACTIVE_INST_VALU; "
-                      "GRBM_GUI_ACTIVE), per-class issue costs from profiles/r02_ubench_issue.txt"}, None
+                      "GRBM_GUI_ACTIVE), per-class issue costs from profiles/r02_ubench_issue.txt "
+                      "and profiles/r03_ubench_int.txt"}, None
 
 
 def kernel_symbol(geo, riding, A):

@@ -19,10 +19,13 @@ namespace mppi {
 // 0xBB67AE85): per round two v_mad_u64_u32 (each yields the high AND the low product word) and
 // two v_bitop3_b32 with truth table 0x96 = a ^ b ^ c, a gfx950 instruction hipcc does not form
 // from `hi ^ ctr ^ key` by itself (it emits two v_xor_b32 each; rocRAND's ten_rounds compiles to
-// 6 VALU per round, this to 4).  Measured (tools/ubench_issue): v_mad_u64_u32 issues in 6.3 SIMD
-// cycles and v_bitop3_b32 in 4.2 -- half rate, about what the two v_xor it replaces cost -- so a
-// round is ~21 cycles and a block with its Box-Muller ~320: that, not the instruction count, is
-// the floor of the noise pass.  The round keys are wave-uniform and stay in SGPRs.
+// 6 VALU per round, this to 4).  Measured (tools/ubench_issue, tools/ubench_int): a round issues in
+// 16.6 SIMD cycles -- v_mad_u64_u32 4.5-4.9, v_bitop3_b32 with its scalar key 4.25 (2.64 with three
+// vector operands: an SGPR operand halves the rate of any VALU instruction) -- and a block with its
+// Box-Muller in ~270: that, not the instruction count, is the floor of the noise pass.  The round
+// keys are wave-uniform and stay in SGPRs: moved to VGPRs (20 v_mov per tile) the kernels got
+// SLOWER, 71.2 against 67.9 us at C3 -- the wave next door issues in the scalar-operand gaps
+// (DESIGN 2.5).
 struct PhiloxAt {
     __device__ __forceinline__ static unsigned int xor3(unsigned int a, unsigned int b,
                                                         unsigned int c)
