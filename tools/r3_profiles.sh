@@ -30,7 +30,10 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(\"$w MPPI_STORE_MODE=$m (1 write-through, 2 non-temporal, 0 the engine's choice by footprint): %.2f us per solve, kernel %.2f us\" % (d[\"ms_per_step\"]*1e3, d[\"roofline\"][\"kernel_ms\"]*1e3))"; done; done; } > gpurun_out/r3/store_mode.txt 2>&1
 python bench.py --workload c1 --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c1.json 2>/dev/null
 python bench.py --force-sharded --no-cpu-baseline --no-pmc > gpurun_out/r3/bench_c2_sharded_1rank.json 2>gpurun_out/r3/bench_fs.err
-for cfg in "2 10000 200 2000" "3 100000 200 500" "1 100 50 2000"; do timeout -k 10 120 tools/latency_probe $cfg; done > gpurun_out/r3/latency_probe.txt
+{ for cfg in "2 10000 200 2000" "3 100000 200 500" "1 100 50 2000" "3 3000 50 2000"; do timeout -k 10 120 tools/latency_probe $cfg; done
+  # the closed loop with a plant step between two calls, the next solve's noise drawn ahead or not
+  for th in 5 20 100; do for pf in 0 1; do for cfg in "2 10000 200 2000" "3 3000 50 2000" "3 100000 200 500"; do
+    echo "MPPI_PREFETCH=$pf plant step $th us:"; MPPI_PREFETCH=$pf timeout -k 10 120 tools/latency_probe $cfg $th; done; done; done; } > gpurun_out/r3/latency_probe.txt
 # config 5: the closed loop (stand-in plant, blocking get_act + set_x per control step), 1 GPU and --gpus all
 g++ -O2 -std=c++17 -I include apps/mppi_closed_loop.cpp -o apps/mppi_closed_loop -L mppi_gpu_amd/lib -lmppi_gpu_amd_sharded -lmppi_gpu_amd -Wl,-rpath,$PWD/mppi_gpu_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib 2>/dev/null
 { apps/mppi_closed_loop --dims 3 --samples 100000 --horizon 200 --seconds 2 | grep -E "RESULT|controller";
