@@ -58,6 +58,14 @@ class PointMassModel:
                 self._lib.mppi_destroy(self._h)
                 self._h = _capi.engine_p()
             raise MppiError(rc, msg)
+        # the closed-loop call's own buffer and argument objects (a.ctypes.data_as per call costs
+        # more than a microsecond; the blocking solve is twenty)
+        self._act = np.empty(self.A, np.float32)
+        self._act_p = _fp(self._act)
+        self._c_get_act = self._lib.mppi_get_act
+        self._xbuf = np.empty(self.S, np.float32)
+        self._xbuf_p = _fp(self._xbuf)
+        self._null_stream = C.c_void_p(0)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -88,8 +96,10 @@ class PointMassModel:
 
     def set_x(self, x):
         """reference src/point_mass.cu:482-486"""
-        x = _f32(x, self.S, "x")
-        check(self._lib.mppi_set_x(self._h, _fp(x)))
+        self._xbuf[...] = _f32(x, self.S, "x")
+        rc = self._lib.mppi_set_x(self._h, self._xbuf_p)
+        if rc != 0:
+            check(rc)
 
     def get_x(self):
         """declared in reference include/point_mass.hpp:34 (never defined there)"""
@@ -100,11 +110,13 @@ class PointMassModel:
     def get_act(self, out=None):
         """One full MPPI solve; reference src/point_mass.cu:129-203. Returns next_act[A]
         (written into `out`, a float32 array of A elements, when given: no allocation per call)."""
-        act = np.empty(self.A, np.float32) if out is None else out
-        rc = self._lib.mppi_get_act(self._h, _fp(act))
+        rc = self._c_get_act(self._h, self._act_p)
         if rc != 0:
             check(rc)
-        return act
+        if out is None:
+            return self._act.copy()
+        out[...] = self._act
+        return out
 
     def get_u(self):
         """reference src/point_mass.cu:488-491"""
@@ -219,15 +231,18 @@ class PointMassModel:
 
     # -- asynchronous / sharded ---------------------------------------------------------------
     def solve_async(self, stream=None):
-        check(self._lib.mppi_solve_async(self._h, C.c_void_p(stream or 0)))
+        rc = self._lib.mppi_solve_async(self._h, C.c_void_p(stream) if stream else self._null_stream)
+        if rc != 0:
+            check(rc)
 
     def flush_async(self):
         check(self._lib.mppi_flush_async(self._h))
 
     def sync_act(self):
-        act = np.empty(self.A, np.float32)
-        check(self._lib.mppi_sync_act(self._h, _fp(act)))
-        return act
+        rc = self._lib.mppi_sync_act(self._h, self._act_p)
+        if rc != 0:
+            check(rc)
+        return self._act.copy()
 
     def partial_len(self):
         return self._lib.mppi_partial_len(self._h)
