@@ -122,14 +122,14 @@ int mppi_set_noise_store(mppi_engine* e, int on);
  * the action of solve j they draw the noise of solve j+1 into a second buffer, in the rollout's own
  * layout, and the next rollout -- stream-ordered behind them, no event, no second queue -- loads it
  * instead of drawing it and computes the same bits (E is a pure function of seed, solve index,
- * sample, step).  mode 1 (default) decides from the host's measured think time between the return
- * of one blocking call and the next solve: launches of one tile per block (a latency chain: K =
- * 1e4, the shipped configs) prefetch when the draw is short (< 1 us) or over before the host is
- * back, longer VALU-bound launches when the think time hides the whole draw (a 100 Hz loop at
- * K = 1e5: yes; calls back to back: no); 0 = never, 2 = whenever possible.  Costs a second noise
- * buffer while in use.  Measured (tools/latency_probe, C ABI): K = 1e4 2-D with a 5..20 us plant
- * step 21.9 -> 19.2..19.5 us per call, the shipped 3-D config 20.3 -> 17.3, K = 1e5 3-D with a
- * 100 us plant step 84 -> 60. */
+ * sample, step).  mode 1 (default): launches of one tile per block (a latency chain that leaves the
+ * chip idle: K = 1e4, the shipped configs) always prefetch -- the draw is over about when the
+ * combine is --, longer VALU-bound launches when the host's measured think time between the return
+ * of one blocking call and the next solve hides the whole draw (a 100 Hz loop at K = 1e5: yes; calls
+ * back to back: no); 0 = never, 2 = whenever possible.  Costs a second noise buffer while in use.
+ * Measured (tools/latency_probe, C ABI): K = 1e4 2-D, calls back to back 20.9-22.0 -> 20.5 us, with
+ * a 5..20 us plant step 21.7-23.5 -> 19.6-19.8; the shipped 3-D config 21.0 -> 18.1; K = 1e5 3-D with
+ * a 100 us plant step 84 -> 60. */
 int mppi_set_noise_prefetch(mppi_engine* e, int mode);
 /* out = { prefetch launches, rollouts that loaded a prefetched buffer } since mppi_create */
 int mppi_get_prefetch_counts(mppi_engine* e, long long out[2]);

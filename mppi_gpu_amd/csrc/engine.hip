@@ -853,24 +853,27 @@ int enqueue_combine(mppi_engine_t* e, hipStream_t st, const float* m, const floa
 }
 
 // Should the combine launch of the blocking call that is about to wait also draw the NEXT solve's
-// noise?  Auto mode: always for launches of one tile per block -- a latency chain that leaves the
-// chip mostly idle -- and for longer (VALU-bound) launches only when the host's think time between
-// two calls has been long enough to hide it.
+// noise?  Auto mode: always for launches of one tile per block, and for longer (VALU-bound)
+// launches only when the host's think time between two calls has been long enough to hide it.
+// (Drawing only the HEAD of a long launch's tiles -- what the idle chip has time for between two
+//  calls back to back -- and letting the sampling kernel load those and draw the rest was built
+//  and measured: the branch costs the sampling kernel 5 % per tile even when nothing was drawn
+//  ahead, and a blocking C3 call got slower, 91.5 against 79.5 us: DESIGN 2.5.)
 bool want_prefetch(const mppi_engine_t* e)
 {
     if (e->pf_mode == 0 || e->injected || e->strict || !e->store_noise || !e->geom_ok || !e->data_set)
         return false;
     if (e->fault || !e->pending || e->pending_mode == 0) return false;
     if (4.0 * (double)e->eint_floats > 1.5e9) return false;     // (a second buffer of that size: no)
-    if (e->pf_mode == 1) {
-        // the Philox + Box-Muller pass alone: 173 ns per wave-block and SIMD.  The
-        // next rollout is stream-ordered behind these blocks: they pay when they are over before
-        // it arrives (the host's think time + its 2.7 us of enqueue), or when they are short
+    if (e->pf_mode == 1 && e->grid != e->n_tileblk) {
+        // A launch of one tile per block is a latency chain that leaves the chip mostly idle: its
+        // draw (write-through stores: no write-back at the end of the launch) is over about when
+        // the combine is, and pays even with calls back to back (C2: 20.5 against 20.9-22.0 us).
+        // A longer launch is VALU-bound: the Philox + Box-Muller pass alone is 173 ns per
+        // wave-block and SIMD, the next rollout is stream-ordered behind it, and it
+        // pays only when the host's think time hides it.
         const double pf_us = (double)e->K * e->NBT / 64.0 * 0.173 / 1024.0;
-        const bool chain = e->grid == e->n_tileblk;      // one tile per block: a latency chain
-        if (chain ? (pf_us > 1.0 && e->think_ema_us < pf_us)
-                  : (e->think_ema_us < 1.5 * pf_us + 20.0))
-            return false;
+        if (e->think_ema_us < 1.5 * pf_us + 20.0) return false;
     }
     return true;
 }

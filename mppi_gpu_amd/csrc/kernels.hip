@@ -318,6 +318,9 @@ template <int A>
 __device__ __forceinline__ void prefetch_body(const PrefetchArgs& p, long long first, long long stride)
 {
     constexpr int BPG = Dim<A>::BPG;
+    // (the engine prefetches buffers below 1.5 GB only: 32-bit byte offsets)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.Eint, 0, (unsigned int)(p.n_slots * 16), 0x00020000);
     for (long long g = first; g < p.n_slots; g += stride) {
         const int lane = (int)(g & 63);
         const long long tq = g >> 6;
@@ -349,7 +352,13 @@ __device__ __forceinline__ void prefetch_body(const PrefetchArgs& p, long long f
             const int n = b * 4 + i;
             e[i] = (n < p.TA) ? p.sig[n % A] * z[i] : 0.0f;    // (a ragged horizon: zero past T)
         }
-        *reinterpret_cast<float4*>(p.Eint + g * 4) = make_float4(e[0], e[1], e[2], e[3]);
+        // write-through (sc0 sc1), like the rollout's own noise stores: what a plain store leaves
+        // dirty in the XCD L2s is written back at the END of the launch, and the next rollout
+        // waits for that end
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        const v4u val = {__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]),
+                         __float_as_uint(e[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (unsigned int)(g * 16), 0, 17);
     }
 }
 

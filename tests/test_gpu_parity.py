@@ -731,21 +731,15 @@ def test_noise_prefetch_gives_the_bits_of_in_kernel_sampling(gpu, A, K, T, packi
 
 
 def test_noise_prefetch_auto_mode_follows_the_launch_length_and_the_think_time(gpu):
-    """mode 1: a launch of one tile per block prefetches when the draw is short (< 1 us: the
-    shipped 3-D config) or over before the host is back; a long (VALU-bound) launch only when the
-    host's think time between two blocking calls hides the whole draw."""
+    """mode 1: a launch of one tile per block always prefetches; a long (VALU-bound) launch only
+    when the host's think time between two blocking calls hides the whole draw."""
     import time
-    c = ol.make_case(3, 1, 50, seed=5, u_scale=0.0)
-    with _model(gpu, 3, 3000, 50, c) as m:               # the shipped config: a 0.3 us draw
-        for _ in range(6):
-            m.get_act()
-        assert m.prefetch_counts()["used"] >= 4
-    c = ol.make_case(2, 1, 200, seed=5, u_scale=0.0)
-    with _model(gpu, 2, 10000, 200, c) as m:             # C2: one tile per block, a 2.6 us draw
-        for _ in range(6):
-            m.get_act()
-            time.sleep(0.0005)
-        assert m.prefetch_counts()["used"] >= 3
+    for A, K, T in ((3, 3000, 50), (2, 10000, 200)):     # the shipped 3-D config, C2
+        c = ol.make_case(A, 1, T, seed=5, u_scale=0.0)
+        with _model(gpu, A, K, T, c) as m:
+            for _ in range(6):
+                m.get_act()
+            assert m.prefetch_counts()["used"] >= 4
     c = ol.make_case(3, 1, 200, seed=5, u_scale=0.0)
     with _model(gpu, 3, 60000, 200, c) as m:             # packed, 6 tiles per block
         for _ in range(6):
