@@ -6,7 +6,7 @@
 // the solve must fit 10 ms.
 //
 //   mppi_closed_loop [-c config.yaml] [-k key] [--dims A] [--samples K] [--horizon T] [--dt 0.1]
-//                    [--model file.xml] [--seconds S] [-t|--traj-save out.csv] [-s|--step-save prefix]
+//                    [--model file.xml] [--seconds S] [--rate-hz R] [-t|--traj-save out.csv] [-s|--step-save prefix]
 //                    [--lambda L] [--noise SIGMA] [--max-a config|LIMIT]
 //                    [--gpus N [--transport collective|direct|copy]]
 // --gpus N (N >= 1, or `all`) runs the controller over N GPUs of this process through
@@ -29,6 +29,7 @@
 #include "point_mass_sharded.hpp"
 
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -99,7 +100,7 @@ int main(int argc, char** argv)
 {
     int A = 3, K = 100000, T = 200;
     float dt = 0.1f, lambda = 1.0f, sigma = 0.025f;
-    double seconds = 2.0;
+    double seconds = 2.0, rate_hz = 0.0;
     std::string model, traj, step_prefix;
     std::vector<float> cfg_goal, cfg_w, cfg_init, cfg_max_a;
     std::string max_a_opt, transport = "collective";
@@ -130,6 +131,7 @@ int main(int argc, char** argv)
         else if (k == "--dt") dt = (float)atof(v.c_str());
         else if (k == "--model") model = v;
         else if (k == "--seconds") seconds = atof(v.c_str());
+        else if (k == "--rate-hz") rate_hz = atof(v.c_str());      // control steps per second of wall time (0: as fast as it goes)
         else if (k == "--traj" || k == "--traj-save" || k == "-t") traj = v;
         else if (k == "--step-save" || k == "-s") step_prefix = v;
         else if (k == "--lambda") { lambda = (float)atof(v.c_str()); lambda_given = true; }
@@ -188,6 +190,7 @@ int main(int argc, char** argv)
 
         xs.push_back(x);
         bool done = false;
+        const auto t_loop0 = std::chrono::steady_clock::now();
         while (!done) {
             model_ctl->get_u(u_prev.data());
             auto t1 = std::chrono::steady_clock::now();
@@ -210,6 +213,9 @@ int main(int argc, char** argv)
             }
             model_ctl->set_x(x.data());
             ++t;
+            if (rate_hz > 0.0)          // a plant that runs in real time: the next step is due at t / rate
+                std::this_thread::sleep_until(t_loop0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                            std::chrono::duration<double>((double)t / rate_hz)));
         }
         return 0;
     };
