@@ -142,7 +142,7 @@ def main():
         # (round 3's bench.py measures traffic / alu / rocprof duration itself, in child passes)
         json.dump(d, open(os.path.join(DST, f"{RR}_{f}.json"), "w"), indent=1)
     extra_txt = ["ubench_issue.txt", "ubench_noise.txt", "latency_probe.txt"] if RND == 2 else \
-                ["latency_probe.txt", "sweep_cost_error.txt", "lambda_speed.txt", "closed_loop.txt", "trace_regions.txt", "soak.txt", "store_mode.txt"]
+                ["latency_probe.txt", "sweep_cost_error.txt", "lambda_speed.txt", "closed_loop.txt", "closed_loop_rates.txt", "trace_regions.txt", "soak.txt", "store_mode.txt"]
     for f in extra_txt:
         txt = [l for l in open(os.path.join(SRC, R, f)).read().splitlines()
                if "warning" not in l and "amdgpu.ids" not in l]

@@ -35,10 +35,11 @@ python bench.py --force-sharded --no-cpu-baseline --no-pmc > gpurun_out/r3/bench
   for th in 5 20 100; do for pf in 0 1; do for cfg in "2 10000 200 2000" "3 3000 50 2000" "3 100000 200 500"; do
     echo "MPPI_PREFETCH=$pf plant step $th us:"; MPPI_PREFETCH=$pf timeout -k 10 120 tools/latency_probe $cfg $th; done; done; done; } > gpurun_out/r3/latency_probe.txt
 # config 5: the closed loop (stand-in plant, blocking get_act + set_x per control step), 1 GPU and --gpus all
-g++ -O2 -std=c++17 -I include apps/mppi_closed_loop.cpp -o apps/mppi_closed_loop -L mppi_gpu_amd/lib -lmppi_gpu_amd_sharded -lmppi_gpu_amd -Wl,-rpath,$PWD/mppi_gpu_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib 2>/dev/null
+g++ -O2 -std=c++17 -I include apps/mppi_closed_loop.cpp -o apps/mppi_closed_loop -L mppi_gpu_amd/lib -lmppi_gpu_amd_sharded -lmppi_gpu_amd -Wl,-rpath,$PWD/mppi_gpu_amd/lib -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib -pthread 2>/dev/null
 { apps/mppi_closed_loop --dims 3 --samples 100000 --horizon 200 --seconds 2 | grep -E "RESULT|controller";
   apps/mppi_closed_loop --dims 3 --samples 100000 --horizon 200 --seconds 2 --gpus all --transport collective | grep -E "RESULT|controller:";
   apps/mppi_closed_loop --dims 2 --samples 10000 --horizon 200 --seconds 2 | grep -E "RESULT"; } > gpurun_out/r3/closed_loop.txt 2>&1
+bash tools/closed_loop_rates.sh > gpurun_out/r3/closed_loop_rates.txt 2>&1
 python tools/sweep_cost_error.py > gpurun_out/r3/sweep_cost_error.txt 2>/dev/null
 python tools/lambda_speed.py > gpurun_out/r3/lambda_speed.txt 2>/dev/null
 { timeout -k 10 300 python tools/soak_packed.py 5000; timeout -k 10 300 python tools/soak.py 50000 4; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r3/soak.txt
