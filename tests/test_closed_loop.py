@@ -98,6 +98,25 @@ def test_closed_loop_config5_meets_100hz_budget(gpu, tmp_path):
     assert rows[0].startswith("x,y,z,vx,vy,vz,ux,uy,uz,size_x,size_u") and len(rows) == steps + 2, len(rows)
 
 
+@pytest.mark.gpu
+def test_closed_loop_paced_in_real_time_draws_the_noise_ahead_with_the_same_trajectory(gpu, tmp_path):
+    """--rate-hz: the plant runs in real time (the reference's MuJoCo loop does), so the host is away
+    between two get_act calls; the engine draws the next solve's noise meanwhile
+    (mppi_set_noise_prefetch, default auto) -- the trajectory must be the one of in-kernel sampling,
+    to the last bit of the CSV."""
+    exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
+    rows = {}
+    for pf in ("0", "1"):
+        traj = tmp_path / f"traj{pf}.csv"
+        out = subprocess.run([exe, "--dims", "3", "--samples", "60000", "--horizon", "200", "--seconds",
+                              "0.6", "--rate-hz", "400", "--traj", str(traj)], capture_output=True,
+                             text=True, env=dict(os.environ, MPPI_PREFETCH=pf))
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert re.search(r"RESULT steps=3[01] ", out.stdout), out.stdout
+        rows[pf] = traj.read_text()
+    assert rows["0"] == rows["1"]
+
+
 def test_driver_rejects_bad_dims_before_touching_anything(tmp_path):
     exe = _cc(os.path.join(ROOT, "apps", "mppi_closed_loop.cpp"), str(tmp_path / "cl"))
     for dims in ("0", "5", "-1"):
