@@ -137,6 +137,7 @@ struct mppi_engine {
     float* d_Einj = nullptr;    // injected noise, [K][T][A]
     bool injected = false, inj_dirty = false;
     bool store_noise = true;    // sampled noise is materialised in d_Eint (mppi_set_noise_store)
+    bool last_injected = false; // the last rollout ran on the caller's noise (d_Einj holds it in E[k][t][a] order)
     bool last_stored = true;    // ... was, by the last rollout; if not, get_inf regenerates it from
     unsigned long long last_seed = 0;       // (seed, solve index, sample offset, sigma) of that rollout
     float last_sigma[4] = {0.f, 0.f, 0.f, 0.f};
@@ -381,6 +382,10 @@ int ensure_geometry(mppi_engine_t* e)
     e->last_E = e->d_Eint;
     HIPCHK(hipMemsetAsync(e->d_Eint, 0, e->eint_floats * sizeof(float), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    // The last solve's noise went with the old layout's buffer: sampled noise is a pure function of
+    // (seed, solve, sample, step) and mppi_get_inf / mppi_get_data regenerate it from here on, bit
+    // for bit; injected noise is read back from the caller's copy (d_Einj, in E[k][t][a] order).
+    e->last_stored = false;
     if (grid > e->part_cap) {
         if (e->d_pm) HIPCHK(hipFree(e->d_pm));
         if (e->d_ps) HIPCHK(hipFree(e->d_ps));
@@ -797,6 +802,7 @@ int enqueue_rollout(mppi_engine_t* e, hipStream_t st, bool carry = false)
     e->last_lay = lay;
     e->last_idx = e->solve_idx;
     e->last_stored = e->injected || e->store_noise || e->strict || use_pf;
+    e->last_injected = e->injected;
     e->last_seed = e->seed;
     for (int i = 0; i < 4; ++i) e->last_sigma[i] = e->sigma[i];
     memcpy(e->x0_last, e->x0, sizeof e->x0);
@@ -1250,6 +1256,9 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
         if (e->last_stored)
             HIPCHK(mppi::launch_export_noise(e->A, e->last_E, e->d_scratch, e->K, e->T, e->last_lay,
                                              e->stream));
+        else if (e->last_injected)      // (its tile buffer went with a geometry change: the caller's copy)
+            HIPCHK(hipMemcpyAsync(e->d_scratch, e->d_Einj, n * sizeof(float), hipMemcpyDeviceToDevice,
+                                  e->stream));
         else     // not materialised by the rollout: the same counters give the same bits again
             HIPCHK(mppi::launch_regen_noise(e->A, e->d_scratch, e->K, e->T, e->last_seed,
                                             e->last_idx, e->k_offset, e->last_sigma, e->stream));
@@ -1261,14 +1270,17 @@ int mppi_get_inf(mppi_engine* e, float* x_all, float* u, float* noise, float* co
     }
     if (x_all) {
         const size_t n = (size_t)e->K * (e->T + 1) * e->S;
-        const size_t ne = e->last_stored ? 0 : (size_t)e->K * e->T * e->A;
+        const size_t ne = (e->last_stored || e->last_injected) ? 0 : (size_t)e->K * e->T * e->A;
         // controls and x0 the last rollout used: U buffer of parity last_idx, x0_last
         if ((rc = ensure_scratch(e, n + 8 + ne))) return rc;
         float* d_x0 = e->d_scratch + n;
         HIPCHK(hipMemcpy(d_x0, e->x0_last, 8 * sizeof(float), hipMemcpyHostToDevice));
         const float* Esrc = e->last_E;
         mppi::ELayout lay = e->last_lay;
-        if (!e->last_stored) {       // regenerate the noise next to the trace, in E[k][t][a] order
+        if (!e->last_stored && e->last_injected) {
+            Esrc = e->d_Einj;
+            lay = mppi::ELayout{2, 1, 0, 0, e->T, 0};
+        } else if (!e->last_stored) {       // regenerate the noise next to the trace, in E[k][t][a] order
             float* d_e = e->d_scratch + n + 8;
             HIPCHK(mppi::launch_regen_noise(e->A, d_e, e->K, e->T, e->last_seed, e->last_idx,
                                             e->k_offset, e->last_sigma, e->stream));

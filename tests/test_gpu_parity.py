@@ -42,7 +42,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -1408,3 +1408,51 @@ def test_randomised_shapes_against_oracle(gpu):
                          tag=f"trial {trial} A{A} K{K} T{T} strict={strict} {geo}")
             done += 1
     assert done >= 60
+
+
+def test_random_api_walks_riding_and_prefetched_equal_flushed(gpu):
+    """tools/fuzz_api.py: seeded random sequences of every C-ABI call that touches the solve state
+    machine (blocking and asynchronous solves, set_x, lambda / sigma / seed changes, noise store,
+    geometry, set_data, flush, every read-out), once with riding combines + forced noise prefetch
+    and once with every combine flushed and no prefetch: every read-out along the way must be
+    equal bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(ROOT, "tools", "fuzz_api.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    used = 0
+    for seed in range(1000, 1012):
+        shape, a, cnt = fz.walk(seed, 50, "A")
+        _, b, _ = fz.walk(seed, 50, "B")
+        used += cnt["used"]
+        assert len(a) == len(b)
+        for i, ((ka, va), (kb, vb)) in enumerate(zip(a, b)):
+            assert ka == kb and np.array_equal(va, vb), (seed, shape, i, ka)
+    assert used > 20
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_read_outs_of_the_last_solve_survive_a_geometry_change(gpu, inject):
+    """set_tuning / set_packing re-plan the tile layout and give the noise buffer a new shape; the
+    noise (and the state trace worked out from it) of the solve BEFORE the change must still be
+    what get_inf hands out: regenerated from the counters, or read from the caller's injected copy
+    (found by tools/fuzz_api.py: the buffer used to come back zeroed)."""
+    A, K, T = 3, 3000, 50
+    c = ol.make_case(A, K, T, seed=77, u_scale=0.03)
+    with _model(gpu, A, K, T, c) as m:
+        m.set_seed(3)
+        if inject:
+            m.set_noise(c["E"])
+        m.memcpy_set_data(c["x0"], c["U"], c["goal"], c["w"])
+        m.get_act()
+        m.get_act()
+        before = m.get_inf()
+        assert np.abs(before["e"]).max() > 0
+        for change in (lambda: m.set_tuning(chunks=0, strict=False, max_blocks=24),
+                       lambda: m.set_packing(4), lambda: m.set_packing(-1)):
+            change()
+            after = m.get_inf()
+            for k in ("e", "x", "u", "cost", "weight"):
+                assert np.array_equal(before[k], after[k]), k
+        m.get_act()                                    # and the next solve runs in the new geometry
+        assert np.isfinite(m.get_u()).all()
