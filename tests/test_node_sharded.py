@@ -247,3 +247,21 @@ def test_closed_loop_app_runs_over_the_sharded_controller(gpu, tmp_path):
     assert "transport collective" in out.stdout
     m = re.search(r"RESULT steps=(\d+) avg_ms=(\S+) worst_ms=(\S+)", out.stdout)
     assert m and int(m.group(1)) >= 10 and float(m.group(3)) < 10.0, out.stdout
+
+
+@pytest.mark.gpu
+def test_random_walks_over_the_sharded_host_direct_equals_copy(gpu):
+    """tools/fuzz_node.py: seeded random sequences of the sharded host's calls (blocking and
+    back-to-back solves, set_x, parameters, seed, injected noise on and off, action limit, set_data,
+    every read-out) with 2 or 3 shard engines on one device, through the in-kernel peer exchange
+    (rides in the next rollout launch) and through peer copies: equal bits at every read-out."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_node", os.path.join(ROOT, "tools", "fuzz_node.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in range(300, 308):
+        shape, a = fz.walk(seed, 40, "direct")
+        _, b = fz.walk(seed, 40, "copy")
+        assert len(a) == len(b)
+        for i, ((ka, va), (kb, vb)) in enumerate(zip(a, b)):
+            assert ka == kb and np.array_equal(va, vb), (seed, shape, i, ka)
