@@ -95,6 +95,7 @@ struct mppi_engine {
     int tune_ride_max_tiles = 2;            // MPPI_RIDE_MAX_TILES: longest launch a combine rides in
     int tune_ride_long = 1;                 // MPPI_RIDE_LONG: packed launches of any length carry it
     int tune_store_mode = 0;                // MPPI_STORE_MODE: 1 write-through, 2 non-temporal noise stores (0 = by size)
+    bool tune_nt_resident_set = false;      // (given explicitly: also used beyond 1.5 GB of noise)
     int tune_nt_resident_mb = 192;          // MPPI_NT_RESIDENT_MB: head of the noise buffer kept write-through in
                                             // mode 2 (it stays in the memory-side cache and is overwritten there by
                                             // the next solve: K = 2e5 129.7 -> 127.8 us; packed kernel only)
@@ -486,7 +487,13 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
         if (e->tune_store_mode > 0 && a.store_e) a.store_e = e->tune_store_mode;
         // bytes of noise one wavefront tile stores: nq float4 per lane
         const double tile_bytes = 1024.0 * (double)(e->nq > 0 ? e->nq : 1);
-        a.nt_from_tile = (long long)((double)e->tune_nt_resident_mb * 1048576.0 / tile_bytes);
+        // the head of the buffer that keeps the write-through store (it stays in the memory-side
+        // cache and is overwritten there by the next solve): 192 MB, +2 % at K = 2e5 (480 MB), nothing
+        // at 960 MB, nothing or 2 % worse at K = 1e6 (2.4 GB: 653 against 641 us on one box, equal
+        // on another) -- none beyond 1.5 GB
+        const double head_mb = (noise_bytes > 1.5e9 && !e->tune_nt_resident_set) ? 0.0
+                                                                                : (double)e->tune_nt_resident_mb;
+        a.nt_from_tile = (long long)(head_mb * 1048576.0 / tile_bytes);
     }
     for (int i = 0; i < e->A; ++i) {
         // scaled state of the packed kernel: d_p = sp (p - g_p), d_v = sv (v - g_v); a zero weight
@@ -954,7 +961,10 @@ int create_common(int K, long long k_offset, bool sharded, int T, float dt, int 
     if (const char* env = getenv("MPPI_RIDE_LONG")) e->tune_ride_long = atoi(env);
     if (const char* env = getenv("MPPI_STORE_MODE")) e->tune_store_mode = atoi(env);
     if (const char* env = getenv("MPPI_PREFETCH")) e->pf_mode = atoi(env);
-    if (const char* env = getenv("MPPI_NT_RESIDENT_MB")) e->tune_nt_resident_mb = atoi(env);
+    if (const char* env = getenv("MPPI_NT_RESIDENT_MB")) {
+        e->tune_nt_resident_mb = atoi(env);
+        e->tune_nt_resident_set = true;
+    }
     e->K = K; e->T = T; e->S = S; e->A = A; e->TA = T * A;
     e->SG = mppi::rollout_group_steps(A);
     e->BPG = mppi::rollout_group_blocks(A);
