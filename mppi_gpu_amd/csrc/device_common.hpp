@@ -76,6 +76,34 @@ __device__ __forceinline__ void box_muller_hw(unsigned int x, unsigned int y, fl
     z1 = __builtin_amdgcn_cosf(th) * s;
 }
 
+// E = sigma * z for the four normals of one Philox block; element i belongs to axis (a0 + i) % A.
+// With ONE sigma for every axis -- the reference's case: its 0.025 is a literal,
+// src/point_mass_gpu.cu:86 -- the factor goes under the square root of the Box-Muller radius,
+// sqrt(sigma^2 (-2 ln u)), and the four multiplies per block are gone (48 of the ~1 700 VALU
+// instructions of a 3-D tile).  `r2c` = -2 ln 2, or -2 ln 2 sigma^2 when `one`: worked out ONCE on
+// the host (noise_radius_factor, kernels.hpp) so that every kernel that draws noise -- the three
+// rollouts, the regeneration for get_inf, the prefetch -- computes the same bits.
+template <int A>
+__device__ __forceinline__ void scaled_normals4(const uint4& r, int a0, bool one, float r2c,
+                                                const float (&sigma)[A], float* e)
+{
+    const float kInv = 2.3283064e-10f;                       // 2^-32
+    const float u0 = fmaf((float)r.x, kInv, kInv), t0 = fmaf((float)r.y, kInv, kInv);
+    const float u1 = fmaf((float)r.z, kInv, kInv), t1 = fmaf((float)r.w, kInv, kInv);
+    const float s0 = __builtin_amdgcn_sqrtf(r2c * __builtin_amdgcn_logf(u0));
+    const float s1 = __builtin_amdgcn_sqrtf(r2c * __builtin_amdgcn_logf(u1));
+    float z[4] = {__builtin_amdgcn_sinf(t0) * s0, __builtin_amdgcn_cosf(t0) * s0,
+                  __builtin_amdgcn_sinf(t1) * s1, __builtin_amdgcn_cosf(t1) * s1};
+    if (one) {                                   // kernel-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = z[i];
+    } else {
+        asm volatile("");                        // (a branch, not a select per normal)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = sigma[(a0 + i) % A] * z[i];
+    }
+}
+
 // Geometry by action dimension.  The noise of one sample and one solve is the flat sequence
 // n = t*A + a; Philox block b holds normals 4b..4b+3.  A GROUP is the smallest run of whole
 // steps that is also a run of whole blocks.
@@ -297,11 +325,10 @@ __device__ __forceinline__ void draw_block(unsigned long long blk, unsigned long
                                            int a0, const RolloutArgs& g, float* e)
 {
     const uint4 r = PhiloxAt::block(blk, kglob, g.seed);
-    float z[4];
-    box_muller_hw(r.x, r.y, z[0], z[1]);
-    box_muller_hw(r.z, r.w, z[2], z[3]);
+    float sg[A];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = g.sigma[(a0 + i) % A] * z[i];
+    for (int i = 0; i < A; ++i) sg[i] = g.sigma[i];
+    scaled_normals4<A>(r, a0 % A, g.sigma_one != 0, g.noise_r2c, sg, e);
 }
 
 struct RunState {

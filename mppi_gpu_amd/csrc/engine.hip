@@ -475,6 +475,7 @@ void fill_rollout_args(const mppi_engine_t* e, mppi::RolloutArgs& a)
     a.pk_nlast = e->T - (e->NGT - 1) * e->SG;
     a.Nrow = e->NBT * 4;
     a.pk_has_cg = 0;
+    a.noise_r2c = mppi::noise_radius_factor(e->sigma, e->A, &a.sigma_one);
     // 0: the sampled noise is not materialised; 1: write-through stores; 2: non-temporal stores.
     // A launch whose noise fits the 256 MB memory-side cache (C3: 240 MB, rewritten by every solve)
     // is best served by write-through; beyond it the stores stream to HBM, and as write-through

@@ -275,9 +275,12 @@ __global__ void k_trace_states(const float* Eint, const float* U, const float* x
 template <int A>
 __global__ void k_regen_noise(float* E, int K, int TA, int NBT, unsigned long long seed,
                               unsigned long long solve_idx, long long k_offset, float s0, float s1,
-                              float s2, float s3)
+                              float s2, float s3, float r2c, int sigma_one)
 {
-    const float sig[4] = {s0, s1, s2, s3};
+    const float sig4[4] = {s0, s1, s2, s3};
+    float sig[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) sig[i] = sig4[i];
     const size_t total = (size_t)K * NBT;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -285,13 +288,12 @@ __global__ void k_regen_noise(float* E, int K, int TA, int NBT, unsigned long lo
         const int b = (int)(idx - (size_t)k * NBT);
         const uint4 r = PhiloxAt::block(solve_idx * (unsigned long long)NBT + (unsigned long long)b,
                                         (unsigned long long)(k_offset + k), seed);
-        float z[4];
-        box_muller_hw(r.x, r.y, z[0], z[1]);
-        box_muller_hw(r.z, r.w, z[2], z[3]);
+        float ev[4];
+        scaled_normals4<A>(r, (b * 4) % A, sigma_one != 0, r2c, sig, ev);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = b * 4 + i;
-            if (n < TA) E[(size_t)k * TA + n] = sig[n % A] * z[i];
+            if (n < TA) E[(size_t)k * TA + n] = ev[i];
         }
     }
 }
@@ -311,6 +313,8 @@ struct PrefetchArgs {
     unsigned long long seed, blk_base;
     long long k_offset;
     float sig[4];
+    float r2c;
+    int sigma_one;
     long long n_slots;
 };
 
@@ -344,13 +348,14 @@ __device__ __forceinline__ void prefetch_body(const PrefetchArgs& p, long long f
         if (!valid) continue;
         const uint4 r = PhiloxAt::block(p.blk_base + (unsigned long long)b,
                                         (unsigned long long)(p.k_offset + k), p.seed);
-        float z[4], e[4];
-        box_muller_hw(r.x, r.y, z[0], z[1]);
-        box_muller_hw(r.z, r.w, z[2], z[3]);
+        float e[4], sg[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) sg[i] = p.sig[i];
+        scaled_normals4<A>(r, (b * 4) % A, p.sigma_one != 0, p.r2c, sg, e);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = b * 4 + i;
-            e[i] = (n < p.TA) ? p.sig[n % A] * z[i] : 0.0f;    // (a ragged horizon: zero past T)
+            e[i] = (n < p.TA) ? e[i] : 0.0f;                   // (a ragged horizon: zero past T)
         }
         // write-through (sc0 sc1), like the rollout's own noise stores: what a plain store leaves
         // dirty in the XCD L2s is written back at the END of the launch, and the next rollout
@@ -669,11 +674,13 @@ hipError_t launch_regen_noise(int A, float* E, int K, int T, unsigned long long 
 {
     const int TA = T * A, NBT = (TA + 3) / 4;
     const int grid = copy_grid((size_t)K * NBT);
+    int one = 0;
+    const float r2c = noise_radius_factor(sg, A, &one);
     switch (A) {
-        case 1: hipLaunchKernelGGL(k_regen_noise<1>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
-        case 2: hipLaunchKernelGGL(k_regen_noise<2>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
-        case 3: hipLaunchKernelGGL(k_regen_noise<3>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
-        case 4: hipLaunchKernelGGL(k_regen_noise<4>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3]); break;
+        case 1: hipLaunchKernelGGL(k_regen_noise<1>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3], r2c, one); break;
+        case 2: hipLaunchKernelGGL(k_regen_noise<2>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3], r2c, one); break;
+        case 3: hipLaunchKernelGGL(k_regen_noise<3>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3], r2c, one); break;
+        case 4: hipLaunchKernelGGL(k_regen_noise<4>, dim3(grid), dim3(256), 0, st, E, K, TA, NBT, seed, solve_idx, k_offset, sg[0], sg[1], sg[2], sg[3], r2c, one); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -694,6 +701,7 @@ hipError_t launch_combine_small_prefetch(int A, const CombineArgs& a, float* Ein
     p.blk_base = solve_idx * (unsigned long long)p.NBT;
     p.k_offset = k_offset;
     for (int i = 0; i < 4; ++i) p.sig[i] = sg[i];
+    p.r2c = noise_radius_factor(sg, A, &p.sigma_one);
     p.n_slots = n_tiles * lay.nq * 64;
     const int n_comb = a.n_cols * a.RS;
     long long nb = (p.n_slots + kRolloutThreads - 1) / kRolloutThreads;

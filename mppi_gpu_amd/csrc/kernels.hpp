@@ -73,6 +73,8 @@ struct RolloutArgs {
     float goal[8];
     float w[8];
     float sigma[4];
+    float noise_r2c;       // Box-Muller radius factor and "one sigma for all axes" (noise_radius_factor)
+    int sigma_one;
     float inv_s[4];
     // packed kernel: dynamics on scaled state d_p = sp (p - g_p), d_v = sv (v - g_v) with
     // sp = sqrt(w_p), sv = sqrt(w_v) (2^-60 where a weight is 0): d_p' = d_p + k1 d_v + k2 a + cg,
@@ -134,6 +136,19 @@ extern unsigned long long* g_mppi_trace_buf;     // [kMaxParts][16], engine.hip
 #else
 #define MPPI_STAMP(i) do { } while (0)
 #endif
+
+// The Box-Muller radius factor every noise-drawing kernel uses (device_common.hpp,
+// scaled_normals4): -2 ln 2, or -2 ln 2 sigma^2 when all axes share one sigma >= 0 (`one`).
+// (MPPI_SIGMA_FOLD=0 in the environment keeps the multiply per normal: an A/B aid, read once)
+inline float noise_radius_factor(const float* sigma, int A, int* one)
+{
+    static const bool allow = !(getenv("MPPI_SIGMA_FOLD") && atoi(getenv("MPPI_SIGMA_FOLD")) == 0);
+    bool same = allow && sigma[0] >= 0.0f;
+    for (int i = 1; i < A; ++i) same = same && sigma[i] == sigma[0];
+    *one = same ? 1 : 0;
+    const double c = -1.3862943611198906;
+    return same ? (float)(c * (double)sigma[0] * (double)sigma[0]) : (float)c;
+}
 
 inline RolloutHot make_hot(const RolloutArgs& a)
 {

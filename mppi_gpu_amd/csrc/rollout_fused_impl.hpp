@@ -126,6 +126,8 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
         x0p[i] = to_vgpr(h.x0[i]);
         x0v[i] = to_vgpr(h.x0[A + i]);
     }
+    const bool sigma_one = g.sigma_one != 0;  // one sigma for all axes: it sits in the radius factor
+    const float noise_r2c = to_vgpr(g.noise_r2c);
     P.dt = to_vgpr(g.dt);
     P.B0 = to_vgpr(g.B0);
     P.dt2 = P.dt * P.dt;
@@ -185,11 +187,7 @@ __device__ __forceinline__ void fused_body(const RolloutHot& h, const DeferredCo
                     float* eq = &e[q * 4];
                     if constexpr (SAMPLE) {
                         const uint4 r = PhiloxAt::block(blk0 + (unsigned long long)q, kglob, seed);
-                        float z[4];
-                        box_muller_hw(r.x, r.y, z[0], z[1]);
-                        box_muller_hw(r.z, r.w, z[2], z[3]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) eq[i] = P.sigma[(q * 4 + i) % A] * z[i];
+                        scaled_normals4<A>(r, (q * 4) % A, sigma_one, noise_r2c, P.sigma, eq);
                         if (store_e && c * nq + q < NBT &&   // blocks past the horizon are not stored
                             !(MPPI_FUSED_LATE_STORE && RIDE && first)) {
                             // Write-through store (sc0 sc1): E is not read again by this

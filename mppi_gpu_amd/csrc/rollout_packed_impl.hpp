@@ -143,6 +143,8 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
     P.dt = to_vgpr(g.dt);
     P.B0 = to_vgpr(g.B0);
     P.dt2 = P.dt * P.dt;
+    const bool sigma_one = g.sigma_one != 0;  // one sigma for all axes: it sits in the radius factor
+    const float noise_r2c = to_vgpr(g.noise_r2c);
     const bool has_cg = g.pk_has_cg != 0;     // wave-uniform: a velocity goal != 0 drifts d_p
     const long long k_cover = g.k_cover;
     const unsigned int cover_and = g.cover_and;
@@ -304,11 +306,7 @@ __device__ __forceinline__ void packed_body(const RolloutHot& h, const DeferredC
                 for (int b = 0; b < BPG; ++b) {
                     const int q = gi * BPG + b;
                     const uint4 r = PhiloxAt::block(blkg + (unsigned long long)b, kg, seed);
-                    float z[4];
-                    box_muller_hw(r.x, r.y, z[0], z[1]);
-                    box_muller_hw(r.z, r.w, z[2], z[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) e[q * 4 + i] = P.sigma[(q * 4 + i) % A] * z[i];
+                    scaled_normals4<A>(r, (q * 4) % A, sigma_one, noise_r2c, P.sigma, &e[q * 4]);
                 }
                 if constexpr (RAGGED) {     // zero the normals past the horizon
                     const int thr = dead_from[gi] * A;
