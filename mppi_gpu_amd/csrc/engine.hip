@@ -280,11 +280,31 @@ int ensure_geometry(mppi_engine_t* e)
                         e->user_packing, e->T, e->A, e->user_packing, e->SG);
         const double util_row = ((double)e->T / e->SG) / ((double)C * ng);
         packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
-        // Packing buys throughput: fewer, fuller tiles.  A launch so short that no block would walk
-        // a second tile (K = 1e4, 2-D: 500 tile groups) is a latency problem instead, and there
-        // the row-aligned kernel's shorter tail wins (measured 12.0 against 14.4 us at C2).
-        if (packed && e->user_packing == 0 && ((long long)e->K + TPW - 1) / TPW <= 4LL * 512)
-            packed = false;
+        // Packing buys throughput: fewer, fuller tiles.  A launch so short that the chip holds all
+        // of its blocks at once is a latency problem instead, and there the row-aligned kernel's
+        // shorter tail wins (12.0 against 14.4 us at C2) -- as long as ITS blocks all fit at once:
+        // 3-D K = 1e4 is 625 row-aligned blocks of which 512 are resident (a second round: 26.0 us)
+        // and 500 packed ones (18.5 us); tools/k_sweep_geometry.py.
+        if (packed && e->user_packing == 0) {
+            int ncu = 256;
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ncu = prop.multiProcessorCount;
+            const int nq_row = ng * e->BPG;
+            const int NBTp_row = (C * nq_row > e->NBT) ? C * nq_row : e->NBT;
+            const size_t lds_row = mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4);
+            const int per_cu_row = lds_row <= mppi::kMaxLdsBytes
+                                       ? mppi::rollout_blocks_per_cu(e->A, NGt, !e->injected, lds_row) : 0;
+            if (per_cu_row <= 0) (void)hipGetLastError();
+            const long long blocks_row = ((long long)e->K * C + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
+            // (... and at no more than ~2.5 blocks per CU: beyond that its waves share the SIMDs
+            //  three and four deep and the chain gets as long as a second round, 938 blocks:
+            //  18-21 us where the packed launch takes 16-18)
+            const long long cap = std::min<long long>((long long)per_cu_row * ncu, 5LL * ncu / 2);
+            const bool row_one_round = per_cu_row > 0 && blocks_row <= cap;
+            if (row_one_round) packed = false;
+        }
         const bool pk_fits = pk_NG > 0 &&
                              mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) <= mppi::kMaxLdsBytes;
         if (packed && e->user_packing <= 0 && !pk_fits)
