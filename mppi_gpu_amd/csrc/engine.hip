@@ -227,10 +227,13 @@ int ensure_geometry(mppi_engine_t* e)
     if (e->geom_ok) return MPPI_OK;
     const int NGT = e->NGT;          // groups per trajectory
     int C, ng, NGt = 0, strict = e->user_strict ? 1 : 0;
+    int C_pref = 0;                  // row-aligned lanes per trajectory of a multi-round launch (auto mode)
+    bool row_one_round = false;      // the row-aligned launch of the chosen C fits the chip at once
     if (strict) {
         C = 1;
         ng = NGT;
     } else {
+        C_pref = 0;
         const int ng_max = mppi::rollout_max_groups(e->A);
         const int Cmin = next_pow2((NGT + ng_max - 1) / ng_max);
         if (Cmin > 64)
@@ -241,6 +244,7 @@ int ensure_geometry(mppi_engine_t* e)
             if (C < Cmin || C > 64 || (C & (C - 1)))
                 return fail(MPPI_EINVAL, "chunks must be a power of two in [%d, 64], got %d", Cmin,
                             C);
+            C_pref = C;
         } else {
             // measured on MI355X (profiles/): lanes that hold <= 7 groups (<= 4 for act_dim 3,
             // whose groups are 3 Philox blocks) keep the kernel at >= 4 waves per SIMD; beyond
@@ -248,12 +252,55 @@ int ensure_geometry(mppi_engine_t* e)
             const int ng_pref = (e->A == 3) ? 4 : 7;
             C = Cmin;
             while (C < 64 && (NGT + C - 1) / C > ng_pref) C <<= 1;
-            while (C < 64 && (long long)e->K * C < 2048LL * 64 && (NGT + 2 * C - 1) / (2 * C) >= 4)
+            // Small launches (tools/chunks_probe.py, 30 shapes x 5 widths): a launch is a latency
+            // chain of ~0.3 us per Philox block of a lane, so MORE lanes per trajectory shorten it
+            // -- while the launch stays at <= 625 blocks, the lane still holds >= 7 blocks (>= 8 to
+            // leave the 16-lane DPP row: the scans then cross rows) and up to 32 lanes (64 never
+            // paid for 3-D / 4-D and 0.5 us at K = 1e3 otherwise).  And FEWER lanes when the launch
+            // would overfill the chip: beyond ~640 blocks the waves share the SIMDs three deep
+            // (4-D K = 7e3: 24.2 us at 32 lanes, 15.2 at 16; 2-D K = 7e3: 14.1 against 10.1).
+            auto blocks_of = [&](int c) { return ((long long)e->K * c + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads; };
+            auto nq_of = [&](int c) { return ((NGT + c - 1) / c) * e->BPG; };
+            C_pref = C;                    // the throughput choice: what a launch of several rounds runs with
+            while (C < 32 && blocks_of(2 * C) <= 625 && nq_of(C) >= (2 * C <= 16 ? 7 : 8) &&
+                   (NGT + 2 * C - 1) / (2 * C) >= 2)
                 C <<= 1;
+            while (C > Cmin && blocks_of(C) > (nq_of(C) <= 8 ? 640 : 512) &&
+                   mppi::rollout_pick_ng_template(e->A, (NGT + C / 2 - 1) / (C / 2)) != 0)
+                C >>= 1;
+            // (C: the candidate for a launch the chip holds at once; whether it does is decided
+            //  below with the occupancy of its kernel, and if not, C_pref runs)
         }
         ng = (NGT + C - 1) / C;
         NGt = mppi::rollout_pick_ng_template(e->A, ng);
         if (!NGt) return fail(MPPI_EINVAL, "no kernel for %d groups per lane", ng);
+        // does the chip hold the candidate's launch at once?  (occupancy of ITS kernel, and no more
+        // than 2.5 blocks per CU -- 2 where a lane holds more than 8 Philox blocks: beyond that
+        // the waves share the SIMDs three and four deep and the chain gets as long as a second
+        // round)  If not, the launch runs several rounds and the throughput choice C_pref is used.
+        if (e->user_chunks == 0) {
+            int ncu = 256;
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                ncu = prop.multiProcessorCount;
+            const int nq_row = ng * e->BPG;
+            const int NBTp_row = (C * nq_row > e->NBT) ? C * nq_row : e->NBT;
+            const size_t lds_row = mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4);
+            const int per_cu_row = lds_row <= mppi::kMaxLdsBytes
+                                       ? mppi::rollout_blocks_per_cu(e->A, NGt, !e->injected, lds_row) : 0;
+            if (per_cu_row <= 0) (void)hipGetLastError();
+            const long long blocks_row = ((long long)e->K * C + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
+            const long long cap = std::min<long long>((long long)per_cu_row * ncu,
+                                                      nq_row <= 8 ? 5LL * ncu / 2 : 2LL * ncu);
+            row_one_round = per_cu_row > 0 && blocks_row <= cap;
+            if (!row_one_round && C != C_pref) {
+                C = C_pref;
+                ng = (NGT + C - 1) / C;
+                NGt = mppi::rollout_pick_ng_template(e->A, ng);
+                if (!NGt) return fail(MPPI_EINVAL, "no kernel for %d groups per lane", ng);
+            }
+        }
     }
     // Packed layout (rollout_packed_impl.hpp): whole trajectories end to end over the lanes of a
     // wavefront.  Needs a horizon of whole groups and non-negative cost weights; taken when it
@@ -282,29 +329,10 @@ int ensure_geometry(mppi_engine_t* e)
         packed = pk_NG > 0 && (e->user_packing > 0 || best > util_row + 0.02);
         // Packing buys throughput: fewer, fuller tiles.  A launch so short that the chip holds all
         // of its blocks at once is a latency problem instead, and there the row-aligned kernel's
-        // shorter tail wins (12.0 against 14.4 us at C2) -- as long as ITS blocks all fit at once:
-        // 3-D K = 1e4 is 625 row-aligned blocks of which 512 are resident (a second round: 26.0 us)
-        // and 500 packed ones (18.5 us); tools/k_sweep_geometry.py.
-        if (packed && e->user_packing == 0) {
-            int ncu = 256;
-            hipDeviceProp_t prop;
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                ncu = prop.multiProcessorCount;
-            const int nq_row = ng * e->BPG;
-            const int NBTp_row = (C * nq_row > e->NBT) ? C * nq_row : e->NBT;
-            const size_t lds_row = mppi::rollout_lds_bytes(NBTp_row, C * nq_row * 4);
-            const int per_cu_row = lds_row <= mppi::kMaxLdsBytes
-                                       ? mppi::rollout_blocks_per_cu(e->A, NGt, !e->injected, lds_row) : 0;
-            if (per_cu_row <= 0) (void)hipGetLastError();
-            const long long blocks_row = ((long long)e->K * C + mppi::kRolloutThreads - 1) / mppi::kRolloutThreads;
-            // (... and at no more than ~2.5 blocks per CU: beyond that its waves share the SIMDs
-            //  three and four deep and the chain gets as long as a second round, 938 blocks:
-            //  18-21 us where the packed launch takes 16-18)
-            const long long cap = std::min<long long>((long long)per_cu_row * ncu, 5LL * ncu / 2);
-            const bool row_one_round = per_cu_row > 0 && blocks_row <= cap;
-            if (row_one_round) packed = false;
-        }
+        // shorter tail wins (12.0 against 14.4 us at C2) -- as long as ITS blocks all fit at once
+        // (row_one_round above): 3-D K = 1e4 is 625 row-aligned blocks of which 512 are resident
+        // (a second round: 26.0 us) and 500 packed ones (18.5 us); tools/k_sweep_geometry.py.
+        if (packed && e->user_packing == 0 && row_one_round) packed = false;
         const bool pk_fits = pk_NG > 0 &&
                              mppi::packed_lds_bytes(e->A, pk_NG, NGT * e->BPG, TPW) <= mppi::kMaxLdsBytes;
         if (packed && e->user_packing <= 0 && !pk_fits)
