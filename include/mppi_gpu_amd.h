@@ -148,7 +148,10 @@ int mppi_set_ref_compat(mppi_engine* e, int on);
  * behaviour. */
 int mppi_set_action_limit(mppi_engine* e, const float* max_a);
 
-/* Kernel shape. chunks = lanes cooperating on one trajectory (power of two, 1..64; 0 = auto);
+/* Kernel shape. chunks = lanes cooperating on one trajectory (power of two, 1..64; 0 = auto: for a
+ * launch the chip holds at once as many lanes, up to 32, as keep a lane at >= 7 Philox blocks and
+ * the launch at <= ~2.5 blocks per CU -- such a launch is a latency chain -- otherwise the width
+ * that keeps the most waves per SIMD);
  * strict != 0 selects the sequential, association-faithful rollout kernel (one lane per
  * trajectory, cost bit-identical to the serial reference arithmetic), used as the parity
  * anchor.  max_blocks caps the persistent grid (0 = auto). */
@@ -157,8 +160,10 @@ int mppi_set_tuning(mppi_engine* e, int chunks, int strict, int max_blocks);
 /* Trajectory packing of the fused rollout.  By default (0) the engine lays whole trajectories
  * end to end over the lanes of a wavefront (a trajectory need not fill a power-of-two number of
  * lanes: T = 200, act_dim 3 uses 97.7 % of the lane-slots instead of 78 %) whenever that wastes
- * fewer slots than `chunks` lanes per trajectory would; needs T a multiple of the group length
- * (4, 2, 4, 1 steps for act_dim 1..4), cost weights >= 0 and chunks == 0.  -1 = never (the
+ * fewer slots than `chunks` lanes per trajectory would AND the row-aligned launch would not fit
+ * the chip at once (a launch that does is a latency problem, where the row-aligned kernel's
+ * shorter tail wins); needs cost weights >= 0 and chunks == 0 (a horizon that is not a multiple of
+ * the group length -- 4, 2, 4, 1 steps for act_dim 1..4 -- has its last group masked).  -1 = never (the
  * row-aligned kernel mppi_set_tuning describes), n > 0 = packed with n groups per lane
  * (MPPI_EINVAL if that size is not built or the problem does not qualify). */
 int mppi_set_packing(mppi_engine* e, int groups_per_lane);
