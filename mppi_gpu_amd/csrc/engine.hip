@@ -265,7 +265,12 @@ int ensure_geometry(mppi_engine_t* e)
             while (C < 32 && blocks_of(2 * C) <= 625 && nq_of(C) >= (2 * C <= 16 ? 7 : 8) &&
                    (NGT + 2 * C - 1) / (2 * C) >= 2)
                 C <<= 1;
+            // (... but no lane of more than 28 steps, what the throughput rule above allows at most:
+            //  the path cost is summed along the lane in one accumulator, and the stated cost bar
+            //  0.35 T 2^-24 is calibrated on lanes of that length -- tools/sweep_auto.py met 5.5e-6
+            //  against a bar of 5.3e-6 at T = 256 with 32 and 64 steps per lane)
             while (C > Cmin && blocks_of(C) > (nq_of(C) <= 8 ? 640 : 512) &&
+                   ((NGT + C / 2 - 1) / (C / 2)) * e->SG <= 28 &&
                    mppi::rollout_pick_ng_template(e->A, (NGT + C / 2 - 1) / (C / 2)) != 0)
                 C >>= 1;
             // (C: the candidate for a launch the chip holds at once; whether it does is decided
