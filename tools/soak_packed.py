@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 bad = 0
 # (A, K, T, packing, lambda)
 for A, K, T, packing, lam in ((3, 100000, 200, 0, 1.0), (3, 100000, 200, 0, 150.0), (3, 30011, 200, 4, 1.0),
-                              (3, 60000, 50, 0, 1.0), (2, 40000, 200, 8, 30.0), (1, 50000, 203, 4, 1.0),
+                              (3, 60000, 50, 4, 1.0), (2, 40000, 200, 8, 30.0), (1, 50000, 203, 4, 1.0),
                               (4, 30000, 37, 10, 5.0)):
     c = ol.make_case(A, 1, T, seed=300 + A, u_scale=0.02)
     res = []
